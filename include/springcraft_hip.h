@@ -1,0 +1,174 @@
+/*
+ * springcraft_hip.h — C ABI of libspringcraft_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for springcraft's one hot path
+ *     C-alpha coordinates -> contact scan -> Kirchhoff / 3x3-block Hessian -> symmetric eigensolve
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference's src/springcraft/).  The reference is pure Python/NumPy and has no FFI; the
+ * binding a maintainer would add is a ctypes stub (shown in INTEGRATION.md and implemented
+ * in springcraft_amd/_hip.py).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no C++ / torch types cross this boundary;
+ *   - every function returns an int status (SC_OK == 0); no exceptions cross the boundary;
+ *     sc_last_error(ctx) returns a human-readable message for the last failure on ctx;
+ *   - "host" entry points take host pointers and do their own transfers;
+ *     "sc_dev_*" entry points take device pointers valid on the context's device and
+ *     enqueue work on the context's stream without synchronising (except where stated);
+ *   - all matrices are float64; Kirchhoff is (n,n), Hessian (3n,3n), C order, exactly as
+ *     numpy returns them in the reference (interaction.py:48,107-109);
+ *   - eigenvectors are returned "rows = modes": V[i*n + c] is component c of mode i, the
+ *     layout of `eig_vectors` in nma.py:63.
+ */
+#ifndef SPRINGCRAFT_HIP_H
+#define SPRINGCRAFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------- */
+#define SC_OK 0
+#define SC_ERR_INVALID_ARG 1   /* bad shape / null pointer / bad enum (-> ValueError)        */
+#define SC_ERR_INDEX 2         /* patch index out of range (-> IndexError, forcefield.py:953) */
+#define SC_ERR_SELF_PAIR 3     /* contact_pair_on with i == j (-> ValueError, interaction.py:210) */
+#define SC_ERR_NO_DEVICE 4     /* no HIP device / wrong architecture                          */
+#define SC_ERR_HIP 5           /* a HIP runtime call failed                                   */
+#define SC_ERR_NOMEM 6         /* device allocation failed                                    */
+#define SC_ERR_NOCONV 7        /* eigensolver failed to converge                              */
+
+/* ---- force-field descriptor ---------------------------------------------------------
+ * Device-side restatement of ForceField.force_constant (forcefield.py:67-94) for the
+ * force fields whose constants depend only on the distance:
+ *   SC_FF_INVARIANT       gamma = 1                       (forcefield.py:264-289)
+ *   SC_FF_HINSEN          d = max(sqrt(d2), 2.9); d < 4 ? 860 d - 2390 : 1.28e6 d^-6
+ *                                                          (forcefield.py:292-330)
+ *   SC_FF_PARAMETER_FREE  gamma = 1 / d2                  (forcefield.py:333-366)
+ * Anything else (TabulatedForceField, user subclasses) goes through the *_from_pairs entry
+ * points: the library returns the ordered pair list + squared distances, the host evaluates
+ * force_constant() and hands gamma[k] back.
+ */
+#define SC_FF_INVARIANT 0
+#define SC_FF_HINSEN 1
+#define SC_FF_PARAMETER_FREE 2
+
+typedef struct sc_ff_desc {
+  int32_t kind;       /* SC_FF_* */
+  int32_t has_cutoff; /* 0: cutoff_distance is None -> every i != j is a contact (interaction.py:151-153) */
+  double cutoff;      /* cutoff_distance in Angstrom (informational) */
+  double cutoff_sq;   /* cutoff_distance**2 evaluated by the host in float64 (interaction.py:166) */
+} sc_ff_desc;
+
+/* ---- contact patches (ForceField.contact_shutdown / contact_pair_off / contact_pair_on,
+ * forcefield.py:96-110; applied in the order of _patch_adjacency_matrix, interaction.py:193-213).
+ * All pointers are host pointers and may be NULL when the matching count is 0.
+ * on_force_constants (PatchedForceField, forcefield.py:183-226): NULL -> switched-on pairs
+ * use the base force field's constant; otherwise one constant per pair_on row (a value of
+ * exactly -1 means "no override", the sentinel of forcefield.py:213-224).
+ * base_cutoff_masks_gamma: 1 -> pairs farther than the cutoff that are in contact only because
+ * of pair_on get gamma = 0 unless overridden (PatchedForceField.force_constant,
+ * forcefield.py:184-196); 0 -> the base force constant is evaluated at any distance. */
+typedef struct sc_patch_desc {
+  int64_t n_shutdown;
+  const int64_t* shutdown; /* (n_shutdown,) atom indices */
+  int64_t n_pair_off;
+  const int64_t* pair_off; /* (n_pair_off, 2) */
+  int64_t n_pair_on;
+  const int64_t* pair_on;  /* (n_pair_on, 2) */
+  const double* on_force_constants; /* (n_pair_on,) or NULL */
+  int32_t base_cutoff_masks_gamma;
+  int32_t reserved;
+} sc_patch_desc;
+
+/* ---- context ---------------------------------------------------------------------------
+ * One context = one device + one stream + a cached device workspace.  Contexts are not
+ * thread-safe; use one per host thread (the reference is single-threaded Python). */
+typedef struct sc_ctx sc_ctx;
+
+int sc_ctx_create(int device, sc_ctx** out);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int sc_ctx_create_on_stream(int device, void* hip_stream, sc_ctx** out);
+void sc_ctx_destroy(sc_ctx* ctx);
+const char* sc_last_error(sc_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int sc_ctx_synchronize(sc_ctx* ctx);
+/* Library / device identification for logs: fills `buf` with e.g. "gfx950 AMD Instinct MI355X, 256 CUs". */
+int sc_device_info(sc_ctx* ctx, char* buf, size_t buflen);
+
+/* ---- contact scan (replaces interaction.py:149-178: adjacency + np.where) ---------------
+ * counts[i] = number of contacts of atom i (row sums of the adjacency matrix, int64, exact);
+ * *n_pairs = total number of directed pairs k. */
+int sc_contacts(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                const sc_patch_desc* patch, int64_t* counts, int64_t* n_pairs);
+
+/* Ordered pair list: pairs is (k,2) int64, sorted by i then j, holding (i,j) and (j,i)
+ * (np.where order, interaction.py:177-178).  sq_dist (k,) may be NULL; it is the reference's
+ * (dx*dx + dy*dy) + dz*dz with separately rounded products (interaction.py:184).
+ * `capacity` is the number of rows the caller allocated; fails with SC_ERR_INVALID_ARG when
+ * the scan finds more. */
+int sc_pairs(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+             const sc_patch_desc* patch, int64_t capacity, int64_t* pairs, double* sq_dist,
+             int64_t* n_pairs);
+
+/* ---- assembly (replaces compute_kirchhoff interaction.py:14-54 and compute_hessian :57-111)
+ * inv_sqrt_mass: NULL, or (n_atoms,) 1/sqrt(m_i): the matrix is multiplied element-wise by
+ * outer(w, w) as GNM.kirchhoff / ANM.hessian do (gnm.py:85-87,104-105; anm.py:89-94,112-113). */
+int sc_kirchhoff_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* kirchhoff);
+int sc_hessian_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                   const sc_patch_desc* patch, const double* inv_sqrt_mass, double* hessian);
+
+/* Host-callback path: the caller supplies the ordered pair list and gamma[k] (any Python
+ * ForceField.force_constant).  Asymmetric gamma is honoured exactly as the reference does:
+ * off-diagonal (i,j) from gamma(i,j), diagonal = -sum over the first index (interaction.py:52,104). */
+int sc_kirchhoff_from_pairs_f64(sc_ctx* ctx, int64_t n_atoms, const int64_t* pairs, int64_t k,
+                                const double* gamma, double* kirchhoff);
+int sc_hessian_from_pairs_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms,
+                              const int64_t* pairs, int64_t k, const double* gamma,
+                              double* hessian);
+
+/* ---- dense symmetric eigensolve (replaces np.linalg.eigh at nma.py:61) -------------------
+ * a: (n,n) symmetric, only the lower triangle is read (UPLO='L', numpy's default); not modified.
+ * w: (n,) ascending eigenvalues.  v: NULL (values only) or (n,n), rows = modes (nma.py:63). */
+int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v);
+
+/* Fused: coordinates -> Hessian (device) -> eigenpairs, no host round trip of the matrix.
+ * Replaces ANM(coord, ff).eigen() (anm.py:150-167 -> nma.py:29-63) for built-in force fields. */
+int sc_anm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v);
+int sc_gnm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v);
+
+/* ---- device-resident / batched entry points (bench + multi-structure sharding) ------------
+ * All pointers are device pointers on the context's device.  Work is enqueued on the context's
+ * stream; nothing synchronises unless stated. */
+
+/* d_coord: (batch, n_atoms, 3) f64.  d_matrix: (batch, dim*n_atoms, dim*n_atoms) f64, dim = 1
+ * (Kirchhoff) or 3 (Hessian).  No patches on this path. d_inv_sqrt_mass: NULL or (batch, n_atoms). */
+int sc_dev_kirchhoff_f64(sc_ctx* ctx, const double* d_coord, int64_t n_atoms, int64_t batch,
+                         const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix);
+int sc_dev_hessian_f64(sc_ctx* ctx, const double* d_coord, int64_t n_atoms, int64_t batch,
+                       const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix);
+
+/* Batched eigensolve of `batch` independent (n,n) symmetric matrices.
+ * d_a: (batch,n,n), lower triangle read, DESTROYED (used as workspace).
+ * d_w: (batch,n).  d_v: NULL or (batch,n,n) rows = modes. */
+int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
+
+/* Bytes of device workspace sc_dev_eigh_f64 will hold for (n, batch) (allocated lazily, cached). */
+int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors);
+
+/* Per-phase device timings (ms, HIP events on the context's stream) of the most recent
+ * sc_dev_eigh_f64 when profiling was enabled with sc_ctx_set_profiling(ctx, 1):
+ * out[0]=tridiagonalisation, out[1]=tridiagonal eigensolver, out[2]=back-transformation,
+ * out[3]=SYMV kernels only (sum), out[4]=SYR2K kernels only (sum), out[5]=reserved. */
+int sc_ctx_set_profiling(sc_ctx* ctx, int enabled);
+int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRINGCRAFT_HIP_H */
