@@ -1,0 +1,256 @@
+"""
+ctypes binding of ``libspringcraft_hip.so`` (C ABI: ``include/springcraft_hip.h``).
+
+This is the only place where Python touches native code.  There is **no CPU fallback**: if the
+shared library is missing, or no gfx950 device is visible, every compute entry point raises
+:class:`HipUnavailableError` — the product path never routes through NumPy or the oracle.
+"""
+
+import ctypes as C
+import os
+from os.path import abspath, dirname, exists, join
+
+import numpy as np
+
+__all__ = ["HipUnavailableError", "lib", "context", "library_path", "EXPORTED_SYMBOLS"]
+
+_PKG = dirname(abspath(__file__))
+_LIB_NAME = "libspringcraft_hip.so"
+
+SC_OK = 0
+SC_ERR_INVALID_ARG = 1
+SC_ERR_INDEX = 2
+SC_ERR_SELF_PAIR = 3
+SC_ERR_NO_DEVICE = 4
+SC_ERR_HIP = 5
+SC_ERR_NOMEM = 6
+SC_ERR_NOCONV = 7
+
+SC_FF_INVARIANT = 0
+SC_FF_HINSEN = 1
+SC_FF_PARAMETER_FREE = 2
+
+# every symbol include/springcraft_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "sc_ctx_create", "sc_ctx_create_on_stream", "sc_ctx_destroy", "sc_last_error",
+    "sc_ctx_synchronize", "sc_device_info", "sc_contacts", "sc_pairs", "sc_kirchhoff_f64",
+    "sc_hessian_f64", "sc_kirchhoff_from_pairs_f64", "sc_hessian_from_pairs_f64", "sc_eigh_f64",
+    "sc_anm_eigen_f64", "sc_gnm_eigen_f64", "sc_dev_kirchhoff_f64", "sc_dev_hessian_f64",
+    "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
+]
+
+
+class HipUnavailableError(RuntimeError):
+    """The HIP extension (or an MI355X device) is not available; there is no fallback."""
+
+
+class FFDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("has_cutoff", C.c_int32),
+        ("cutoff", C.c_double),
+        ("cutoff_sq", C.c_double),
+    ]
+
+
+class PatchDesc(C.Structure):
+    _fields_ = [
+        ("n_shutdown", C.c_int64),
+        ("shutdown", C.c_void_p),
+        ("n_pair_off", C.c_int64),
+        ("pair_off", C.c_void_p),
+        ("n_pair_on", C.c_int64),
+        ("pair_on", C.c_void_p),
+        ("on_force_constants", C.c_void_p),
+        ("base_cutoff_masks_gamma", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def library_path():
+    return os.environ.get("SPRINGCRAFT_HIP_LIB", join(_PKG, _LIB_NAME))
+
+
+def lib():
+    """Load (once) and return the ctypes handle, with argument types declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not exists(path):
+        raise HipUnavailableError(
+            f"{path} not found: build it with `python springcraft_amd/csrc/build.py` "
+            "(there is no CPU fallback)"
+        )
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # e.g. ROCm runtime missing
+        raise HipUnavailableError(f"cannot load {path}: {e}") from e
+
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    P = C.POINTER
+    sig = {
+        "sc_ctx_create": (i32, [i32, P(vp)]),
+        "sc_ctx_create_on_stream": (i32, [i32, vp, P(vp)]),
+        "sc_ctx_destroy": (None, [vp]),
+        "sc_last_error": (C.c_char_p, [vp]),
+        "sc_ctx_synchronize": (i32, [vp]),
+        "sc_device_info": (i32, [vp, C.c_char_p, C.c_size_t]),
+        "sc_contacts": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, P(i64)]),
+        "sc_pairs": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), i64, vp, vp, P(i64)]),
+        "sc_kirchhoff_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, vp]),
+        "sc_hessian_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, vp]),
+        "sc_kirchhoff_from_pairs_f64": (i32, [vp, i64, vp, i64, vp, vp]),
+        "sc_hessian_from_pairs_f64": (i32, [vp, vp, i64, vp, i64, vp, vp]),
+        "sc_eigh_f64": (i32, [vp, vp, i64, vp, vp]),
+        "sc_anm_eigen_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, vp, vp]),
+        "sc_gnm_eigen_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, vp, vp]),
+        "sc_dev_kirchhoff_f64": (i32, [vp, vp, i64, i64, P(FFDesc), vp, vp]),
+        "sc_dev_hessian_f64": (i32, [vp, vp, i64, i64, P(FFDesc), vp, vp]),
+        "sc_dev_eigh_f64": (i32, [vp, vp, i64, i64, vp, vp]),
+        "sc_eigh_workspace_bytes": (i64, [i64, i64, i32]),
+        "sc_ctx_set_profiling": (i32, [vp, i32]),
+        "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class Context:
+    """Owns one ``sc_ctx`` (device + stream + cached workspace)."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        h = C.c_void_p()
+        if stream is None:
+            rc = L.sc_ctx_create(int(device), C.byref(h))
+        else:
+            rc = L.sc_ctx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
+        if rc == SC_ERR_NO_DEVICE:
+            raise HipUnavailableError(
+                f"no gfx950 (MI355X) device {device} visible to HIP; springcraft_amd has no CPU fallback"
+            )
+        if rc != SC_OK:
+            raise HipUnavailableError(f"sc_ctx_create failed with status {rc}")
+        self._h = h
+        self._L = L
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc):
+        """Map a C status to the exception type the reference raises at the same place."""
+        if rc == SC_OK:
+            return
+        msg = self._L.sc_last_error(self._h)
+        msg = msg.decode() if msg else f"status {rc}"
+        if rc in (SC_ERR_INVALID_ARG, SC_ERR_SELF_PAIR):
+            raise ValueError(msg)
+        if rc == SC_ERR_INDEX:
+            raise IndexError(msg)
+        if rc == SC_ERR_NOMEM:
+            raise MemoryError(msg)
+        raise RuntimeError(f"springcraft_hip: {msg} (status {rc})")
+
+    def synchronize(self):
+        self.check(self._L.sc_ctx_synchronize(self._h))
+
+    def info(self):
+        buf = C.create_string_buffer(256)
+        self.check(self._L.sc_device_info(self._h, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._L.sc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context(device=None):
+    """Process-wide cached context for ``device`` (default: ``SPRINGCRAFT_HIP_DEVICE`` or 0)."""
+    if device is None:
+        device = int(os.environ.get("SPRINGCRAFT_HIP_DEVICE", "0"))
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    return ctx
+
+
+# ---- small helpers used by the host modules -------------------------------------------------
+
+def ptr(a):
+    """Host pointer of a C-contiguous NumPy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return C.c_void_p(a.ctypes.data)
+
+
+def make_ff_desc(kind, cutoff_distance):
+    d = FFDesc()
+    d.kind = kind
+    if cutoff_distance is None:
+        d.has_cutoff = 0
+        d.cutoff = float("nan")
+        d.cutoff_sq = float("nan")
+    else:
+        d.has_cutoff = 1
+        d.cutoff = float(cutoff_distance)
+        # interaction.py:166 squares the cutoff in Python / NumPy float64 arithmetic
+        d.cutoff_sq = float(np.float64(cutoff_distance) ** 2)
+    return d
+
+
+def make_patch_desc(shutdown, pair_off, pair_on, on_force_constants, mask_gamma, keep):
+    """
+    Build an ``sc_patch_desc``; ``keep`` is a list that receives the arrays whose memory the
+    descriptor points into (so they outlive the call).
+    """
+    if shutdown is None and pair_off is None and pair_on is None:
+        return None
+    d = PatchDesc()
+
+    def arr(x, cols):
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.int64))
+        a = a.reshape(-1, cols) if cols > 1 else a.reshape(-1)
+        keep.append(a)
+        return a
+
+    if shutdown is not None:
+        a = arr(shutdown, 1)
+        d.n_shutdown, d.shutdown = len(a), a.ctypes.data
+    if pair_off is not None:
+        a = arr(pair_off, 2)
+        d.n_pair_off, d.pair_off = len(a), a.ctypes.data
+    if pair_on is not None:
+        a = arr(pair_on, 2)
+        d.n_pair_on, d.pair_on = len(a), a.ctypes.data
+        if on_force_constants is not None:
+            g = np.ascontiguousarray(np.asarray(on_force_constants, dtype=np.float64)).reshape(-1)
+            if len(g) != len(a):
+                raise IndexError(
+                    f"{len(g)} force constants were given for {len(a)} switched on contact_pairs"
+                )
+            keep.append(g)
+            d.on_force_constants = g.ctypes.data
+    d.base_cutoff_masks_gamma = 1 if mask_gamma else 0
+    return d

@@ -1,0 +1,129 @@
+"""
+Shared machinery of the :class:`~springcraft_amd.GNM` / :class:`~springcraft_amd.ANM` model
+objects: mass handling, lazily cached matrix <-> covariance pair, and the device eigensolve.
+(The reference duplicates this logic in gnm.py:58-143 and anm.py:62-148.)
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip, atoms as _atoms
+from .forcefield import device_plan
+from .interaction import _assemble, _normalised_patch, _validated_coord
+
+# Average masses (u) of the 20 canonical amino acids as free molecules, i.e. what
+# ``biotite.structure.info.mass(res_name, is_residue=True)`` reports from the PDB chemical
+# component dictionary; used for ``masses=True`` only when biotite itself is not installed.
+_RESIDUE_MASS = {
+    "ALA": 89.093, "ARG": 175.209, "ASN": 132.118, "ASP": 133.103, "CYS": 121.158,
+    "GLN": 146.144, "GLU": 147.129, "GLY": 75.067, "HIS": 156.162, "ILE": 131.173,
+    "LEU": 131.173, "LYS": 147.195, "MET": 149.211, "PHE": 165.189, "PRO": 115.130,
+    "SER": 105.093, "THR": 119.119, "TRP": 204.225, "TYR": 181.189, "VAL": 117.146,
+}
+
+
+def residue_mass(res_name):
+    try:
+        import biotite.structure.info as info  # optional dependency
+
+        return info.mass(res_name, is_residue=True)
+    except ImportError:
+        return _RESIDUE_MASS[res_name]
+
+
+class ElasticNetworkModel:
+    """Base of GNM (dim=1) and ANM (dim=3)."""
+
+    _dim = 1
+
+    def __init__(self, atoms, force_field, masses=None, use_cell_list=True):
+        self._coord = _atoms.coord(atoms)
+        self._ff = force_field
+        self._use_cell_list = use_cell_list
+
+        # anm.py:67-87 / gnm.py:63-83
+        if masses is None or masses is False:
+            self._masses = None
+        elif masses is True:
+            if not _atoms.is_atom_array(atoms):
+                raise TypeError("An AtomArray is required to automatically infer masses")
+            self._masses = np.array([residue_mass(r) for r in atoms.res_name])
+        else:
+            # like the reference, a mass array needs an atom container (atoms.array_length())
+            if len(masses) != atoms.array_length():
+                raise IndexError(f"{len(masses)} masses for {atoms.array_length()} atoms given")
+            if np.any(np.asarray(masses) == 0):
+                raise ValueError("Masses must not be 0")
+            self._masses = np.array(masses, dtype=float)
+
+        self._inv_sqrt_mass = None if self._masses is None else 1 / np.sqrt(self._masses)
+        self._matrix = None
+        self._covariance = None
+
+    @property
+    def masses(self):
+        return self._masses
+
+    def _size(self):
+        return len(self._coord) * self._dim
+
+    # ---- matrix <-> covariance, lazily cached (anm.py:105-148) --------------------------------
+    def _get_matrix(self):
+        if self._matrix is None:
+            if self._covariance is None:
+                self._matrix, _ = _assemble(self._coord, self._ff, self._dim, self._inv_sqrt_mass)
+            else:
+                self._matrix = np.linalg.pinv(self._covariance, hermitian=True, rcond=1e-6)
+        return self._matrix
+
+    def _set_matrix(self, value, error=IndexError):
+        n = self._size()
+        if value.shape != (n, n):
+            raise error(f"Expected shape {(n, n)}, got {value.shape}")
+        self._matrix = value
+        self._covariance = None
+
+    def _get_covariance(self):
+        if self._covariance is None:
+            self._covariance = np.linalg.pinv(self._get_matrix(), hermitian=True, rcond=1e-6)
+        return self._covariance
+
+    def _set_covariance(self, value):
+        n = self._size()
+        if value.shape != (n, n):
+            raise IndexError(f"Expected shape {(n, n)}, got {value.shape}")
+        self._covariance = value
+        self._matrix = None
+
+    # ---- eigensolve ---------------------------------------------------------------------------
+    def _eigen_device(self):
+        """
+        (eig_values, eig_vectors[rows]) on the device.  When the matrix has not been materialised
+        on the host and the force field is evaluated on device, assembly and eigensolve are fused
+        (coordinates in, eigenpairs out: the matrix never crosses PCIe); otherwise the host
+        matrix (possibly user-assigned, anm.py:120-130) is solved as it is.
+        """
+        from . import nma
+
+        if self._matrix is None and self._covariance is None:
+            ff_desc, patch, fused = device_plan(self._ff)
+            if fused:
+                coord = _validated_coord(self._coord, self._ff)
+                n = len(coord)
+                keep = []
+                patch_desc = _normalised_patch(patch, n, keep)
+                pd = C.byref(patch_desc) if patch_desc is not None else None
+                ctx = _hip.context()
+                L = _hip.lib()
+                m = n * self._dim
+                w = np.empty(m)
+                v = np.empty((m, m))
+                ism = None
+                if self._inv_sqrt_mass is not None:
+                    ism = np.ascontiguousarray(self._inv_sqrt_mass, dtype=np.float64)
+                fn = L.sc_anm_eigen_f64 if self._dim == 3 else L.sc_gnm_eigen_f64
+                ctx.check(fn(ctx.handle, _hip.ptr(coord), n, C.byref(ff_desc), pd, _hip.ptr(ism),
+                             _hip.ptr(w), _hip.ptr(v)))
+                return w, v
+        return nma.eigh(self._get_matrix())

@@ -1,0 +1,527 @@
+// C-ABI entry points of libspringcraft_hip.so (declared in include/springcraft_hip.h).
+// Host-side plumbing only: argument validation, patch-table construction, transfers and
+// kernel sequencing.  All arithmetic lives in assembly.hip / the eigensolver units.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "common.h"
+
+int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int sc_reserve_ws(sc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return SC_OK;
+  if (ctx->ws) {
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  SC_HIP(ctx, hipMalloc(&ctx->ws, bytes));
+  ctx->ws_bytes = bytes;
+  return SC_OK;
+}
+
+int sc_reserve_scratch(sc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return SC_OK;
+  if (ctx->scratch) {
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  SC_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return SC_OK;
+}
+
+namespace {
+
+int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
+  if (!out) return SC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return SC_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SC_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SC_ERR_NO_DEVICE;  // gfx950 code objects only
+  if (hipSetDevice(device) != hipSuccess) return SC_ERR_NO_DEVICE;
+  sc_ctx* ctx = new sc_ctx();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (own) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return SC_ERR_HIP;
+    }
+    ctx->own_stream = true;
+  } else {
+    ctx->stream = (hipStream_t)stream;
+  }
+  *out = ctx;
+  return SC_OK;
+}
+
+int check_ff(sc_ctx* ctx, const sc_ff_desc* ff) {
+  if (!ff) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "force-field descriptor is NULL");
+  if (ff->kind < SC_FF_INVARIANT || ff->kind > SC_FF_PARAMETER_FREE)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "unknown force-field kind %d", ff->kind);
+  if (ff->kind == SC_FF_INVARIANT && !ff->has_cutoff)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "Cutoff distance must be a float");  // forcefield.py:277-281
+  return SC_OK;
+}
+
+struct Bump {  // carves sub-buffers out of ctx->scratch
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct HostPatch {
+  bool any = false;
+  std::vector<uint8_t> shut;
+  std::vector<int32_t> row_ptr, col;
+  std::vector<int8_t> flag;
+  std::vector<double> gam;
+  int mask_gamma = 0;
+  size_t device_bytes() const {
+    return align_up(shut.size(), 256) + align_up(row_ptr.size() * 4, 256) +
+           align_up(col.size() * 4 + 4, 256) + align_up(flag.size() + 1, 256) +
+           align_up(gam.size() * 8 + 8, 256) + 2048;
+  }
+};
+
+// Restates _patch_adjacency_matrix (interaction.py:193-213) + the patch-matrix construction of
+// PatchedForceField.force_constant (forcefield.py:199-224) as a per-row override table.
+int build_patch(sc_ctx* ctx, const sc_patch_desc* pd, int64_t n, HostPatch& hp) {
+  hp.any = false;
+  if (!pd || (pd->n_shutdown == 0 && pd->n_pair_off == 0 && pd->n_pair_on == 0)) return SC_OK;
+  if (pd->n_shutdown < 0 || pd->n_pair_off < 0 || pd->n_pair_on < 0 ||
+      (pd->n_shutdown && !pd->shutdown) || (pd->n_pair_off && !pd->pair_off) ||
+      (pd->n_pair_on && !pd->pair_on))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "inconsistent patch descriptor");
+  hp.any = true;
+  hp.mask_gamma = pd->base_cutoff_masks_gamma;
+  hp.shut.assign((size_t)n, 0);
+  auto in_range = [&](int64_t v) { return v >= 0 && v < n; };
+  for (int64_t s = 0; s < pd->n_shutdown; ++s) {
+    if (!in_range(pd->shutdown[s]))
+      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
+                          (long long)pd->shutdown[s], (long long)n);
+    hp.shut[(size_t)pd->shutdown[s]] = 1;
+  }
+  struct Ov { int8_t flag; double gam; };
+  std::map<std::pair<int32_t, int32_t>, Ov> ov;
+  auto touch = [&](int64_t i, int64_t j) -> Ov& {
+    auto key = std::make_pair((int32_t)i, (int32_t)j);
+    auto it = ov.find(key);
+    if (it == ov.end()) it = ov.emplace(key, Ov{0, -1.0}).first;
+    return it->second;
+  };
+  for (int64_t p = 0; p < pd->n_pair_off; ++p) {
+    const int64_t i = pd->pair_off[2 * p], j = pd->pair_off[2 * p + 1];
+    if (!in_range(i) || !in_range(j))
+      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
+                          (long long)(in_range(i) ? j : i), (long long)n);
+    touch(i, j).flag = 0;
+    touch(j, i).flag = 0;
+  }
+  for (int64_t p = 0; p < pd->n_pair_on; ++p) {
+    const int64_t i = pd->pair_on[2 * p], j = pd->pair_on[2 * p + 1];
+    if (!in_range(i) || !in_range(j))
+      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
+                          (long long)(in_range(i) ? j : i), (long long)n);
+    if (i == j)
+      return sc_set_error(ctx, SC_ERR_SELF_PAIR, "Cannot turn on interaction of an atom with itself");
+  }
+  // numpy assignment order: matrix[i, j] = v for all rows, then matrix[j, i] = v for all rows
+  for (int pass = 0; pass < 2; ++pass)
+    for (int64_t p = 0; p < pd->n_pair_on; ++p) {
+      const int64_t i = pd->pair_on[2 * p + pass], j = pd->pair_on[2 * p + 1 - pass];
+      Ov& o = touch(i, j);
+      o.flag = 1;
+      if (pd->on_force_constants) o.gam = pd->on_force_constants[p];
+    }
+  hp.row_ptr.assign((size_t)n + 1, 0);
+  for (auto& kv : ov) hp.row_ptr[(size_t)kv.first.first + 1]++;
+  for (int64_t i = 0; i < n; ++i) hp.row_ptr[i + 1] += hp.row_ptr[i];
+  hp.col.reserve(ov.size());
+  hp.flag.reserve(ov.size());
+  hp.gam.reserve(ov.size());
+  for (auto& kv : ov) {  // std::map iterates sorted by (i, j): already CSR order
+    hp.col.push_back(kv.first.second);
+    hp.flag.push_back(kv.second.flag);
+    hp.gam.push_back(kv.second.gam == -1.0 ? std::nan("") : kv.second.gam);  // forcefield.py:221-224
+  }
+  return SC_OK;
+}
+
+int upload_patch(sc_ctx* ctx, const HostPatch& hp, Bump& bump, PatchDev& dev) {
+  uint8_t* d_shut = bump.take<uint8_t>(hp.shut.size());
+  int32_t* d_rp = bump.take<int32_t>(hp.row_ptr.size());
+  int32_t* d_col = bump.take<int32_t>(hp.col.size() + 1);
+  int8_t* d_flag = bump.take<int8_t>(hp.flag.size() + 1);
+  double* d_gam = bump.take<double>(hp.gam.size() + 1);
+  SC_HIP(ctx, hipMemcpyAsync(d_shut, hp.shut.data(), hp.shut.size(), hipMemcpyHostToDevice, ctx->stream));
+  SC_HIP(ctx, hipMemcpyAsync(d_rp, hp.row_ptr.data(), hp.row_ptr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!hp.col.empty()) {
+    SC_HIP(ctx, hipMemcpyAsync(d_col, hp.col.data(), hp.col.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_flag, hp.flag.data(), hp.flag.size(), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_gam, hp.gam.data(), hp.gam.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  // the source vectors must outlive the async copies
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev = PatchDev{d_shut, d_rp, d_col, d_flag, d_gam, hp.mask_gamma};
+  return SC_OK;
+}
+
+int check_coord_args(sc_ctx* ctx, const double* coord, int64_t n) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || n > 2000000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad atom count %lld", (long long)n);
+  if (n > 0 && !coord) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "coord is NULL");
+  return SC_OK;
+}
+
+// Shared body of sc_kirchhoff_f64 / sc_hessian_f64 / sc_contacts / fused eigen entry points:
+// stages coord (+ weights, patches) into scratch, returns device pointers.
+struct Staged {
+  double* d_coord = nullptr;
+  double* d_w = nullptr;
+  PatchDev patch{};
+  bool has_patch = false;
+  HostPatch hp;  // keeps host vectors alive until the stream is synchronised
+};
+
+int stage_inputs(sc_ctx* ctx, const double* coord, int64_t n, const sc_patch_desc* pd,
+                 const double* inv_sqrt_mass, size_t extra_bytes, Staged& st, Bump& bump) {
+  SC_TRY(build_patch(ctx, pd, n, st.hp));
+  size_t need = align_up((size_t)n * 24, 256) + align_up((size_t)n * 8, 256) + 1024 + extra_bytes;
+  if (st.hp.any) need += st.hp.device_bytes();
+  SC_TRY(sc_reserve_scratch(ctx, need));
+  bump.base = (char*)ctx->scratch;
+  bump.off = 0;
+  st.d_coord = bump.take<double>((size_t)n * 3);
+  SC_HIP(ctx, hipMemcpyAsync(st.d_coord, coord, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  if (inv_sqrt_mass) {
+    st.d_w = bump.take<double>((size_t)n);
+    SC_HIP(ctx, hipMemcpyAsync(st.d_w, inv_sqrt_mass, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (st.hp.any) {
+    SC_TRY(upload_patch(ctx, st.hp, bump, st.patch));
+    st.has_patch = true;
+  }
+  return SC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sc_ctx_create(int device, sc_ctx** out) { return ctx_create_impl(device, nullptr, true, out); }
+
+int sc_ctx_create_on_stream(int device, void* hip_stream, sc_ctx** out) {
+  return ctx_create_impl(device, hip_stream, false, out);
+}
+
+void sc_ctx_destroy(sc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sc_ctx_synchronize(sc_ctx* ctx) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_device_info(sc_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || buflen == 0) return SC_ERR_INVALID_ARG;
+  hipDeviceProp_t prop;
+  SC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s %s, %d CUs, %.0f GiB", prop.gcnArchName, prop.name,
+           prop.multiProcessorCount, (double)prop.totalGlobalMem / (1 << 30));
+  return SC_OK;
+}
+
+int sc_ctx_set_profiling(sc_ctx* ctx, int enabled) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  ctx->profiling = enabled != 0;
+  return SC_OK;
+}
+
+int sc_last_eigh_timings(sc_ctx* ctx, double* out6) {
+  if (!ctx || !out6) return SC_ERR_INVALID_ARG;
+  for (int i = 0; i < 6; ++i) out6[i] = ctx->last_timings[i];
+  return SC_OK;
+}
+
+int sc_contacts(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                const sc_patch_desc* patch, int64_t* counts, int64_t* n_pairs) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_pairs) *n_pairs = 0;
+  if (n == 0) return SC_OK;
+  Staged st;
+  Bump bump{};
+  SC_TRY(stage_inputs(ctx, coord, n, patch, nullptr, (size_t)n * 8 + 256, st, bump));
+  int64_t* d_counts = bump.take<int64_t>((size_t)n);
+  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, *ff, st.has_patch ? &st.patch : nullptr, d_counts));
+  std::vector<int64_t> h((size_t)n);
+  SC_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t total = 0;
+  for (int64_t i = 0; i < n; ++i) total += h[(size_t)i];
+  if (counts) std::memcpy(counts, h.data(), (size_t)n * 8);
+  if (n_pairs) *n_pairs = total;
+  return SC_OK;
+}
+
+int sc_pairs(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+             const sc_patch_desc* patch, int64_t capacity, int64_t* pairs, double* sq_dist,
+             int64_t* n_pairs) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  if (capacity < 0 || (capacity > 0 && !pairs))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pairs buffer is NULL");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_pairs) *n_pairs = 0;
+  if (n == 0) return SC_OK;
+  Staged st;
+  Bump bump{};
+  const size_t extra = (size_t)(2 * n + 2) * 8 + (size_t)capacity * 24 + 2048;
+  SC_TRY(stage_inputs(ctx, coord, n, patch, nullptr, extra, st, bump));
+  int64_t* d_counts = bump.take<int64_t>((size_t)n);
+  int64_t* d_off = bump.take<int64_t>((size_t)n + 1);
+  int64_t* d_pairs = bump.take<int64_t>((size_t)capacity * 2 + 2);
+  double* d_sq = sq_dist ? bump.take<double>((size_t)capacity + 1) : nullptr;
+  const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
+  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, *ff, pdev, d_counts));
+  std::vector<int64_t> h((size_t)n + 1);
+  SC_HIP(ctx, hipMemcpyAsync(h.data() + 1, d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  h[0] = 0;
+  for (int64_t i = 0; i < n; ++i) h[(size_t)i + 1] += h[(size_t)i];
+  const int64_t k = h[(size_t)n];
+  if (n_pairs) *n_pairs = k;
+  if (k > capacity)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pair buffer too small: %lld > %lld", (long long)k,
+                        (long long)capacity);
+  if (k == 0) return SC_OK;
+  SC_HIP(ctx, hipMemcpyAsync(d_off, h.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  SC_TRY(launch_pair_fill(ctx, st.d_coord, n, *ff, pdev, d_off, d_pairs, d_sq));
+  SC_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, (size_t)k * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (sq_dist)
+    SC_HIP(ctx, hipMemcpyAsync(sq_dist, d_sq, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+static int assemble_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                         const sc_patch_desc* patch, const double* inv_sqrt_mass, double* out,
+                         int dim) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  if (n > 0 && !out) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "output matrix is NULL");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const size_t elems = (size_t)n * n * dim * dim;
+  Staged st;
+  Bump bump{};
+  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass, elems * 8 + 512, st, bump));
+  double* d_m = bump.take<double>(elems);
+  const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
+  if (dim == 1)
+    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m, nullptr));
+  else
+    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m));
+  SC_HIP(ctx, hipMemcpyAsync(out, d_m, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_kirchhoff_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* kirchhoff) {
+  return assemble_host(ctx, coord, n, ff, patch, inv_sqrt_mass, kirchhoff, 1);
+}
+
+int sc_hessian_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                   const sc_patch_desc* patch, const double* inv_sqrt_mass, double* hessian) {
+  return assemble_host(ctx, coord, n, ff, patch, inv_sqrt_mass, hessian, 3);
+}
+
+static int check_pairs(sc_ctx* ctx, int64_t n, const int64_t* pairs, int64_t k, const double* gamma) {
+  if (k < 0 || (k > 0 && (!pairs || !gamma)))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pairs / gamma is NULL");
+  for (int64_t p = 0; p < 2 * k; ++p)
+    if (pairs[p] < 0 || pairs[p] >= n)
+      return sc_set_error(ctx, SC_ERR_INDEX, "pair index %lld out of range for %lld atoms",
+                          (long long)pairs[p], (long long)n);
+  return SC_OK;
+}
+
+int sc_kirchhoff_from_pairs_f64(sc_ctx* ctx, int64_t n, const int64_t* pairs, int64_t k,
+                                const double* gamma, double* kirchhoff) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && !kirchhoff)) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_TRY(check_pairs(ctx, n, pairs, k, gamma));
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const size_t elems = (size_t)n * n;
+  SC_TRY(sc_reserve_scratch(ctx, elems * 8 + (size_t)k * 24 + 4096));
+  Bump bump{(char*)ctx->scratch};
+  double* d_m = bump.take<double>(elems);
+  int64_t* d_pairs = bump.take<int64_t>((size_t)k * 2 + 2);
+  double* d_g = bump.take<double>((size_t)k + 1);
+  if (k > 0) {
+    SC_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, (size_t)k * 16, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_g, gamma, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SC_TRY(launch_kirchhoff_from_pairs(ctx, n, d_pairs, k, d_g, d_m));
+  SC_HIP(ctx, hipMemcpyAsync(kirchhoff, d_m, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_hessian_from_pairs_f64(sc_ctx* ctx, const double* coord, int64_t n, const int64_t* pairs,
+                              int64_t k, const double* gamma, double* hessian) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  if (n > 0 && !hessian) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "output matrix is NULL");
+  SC_TRY(check_pairs(ctx, n, pairs, k, gamma));
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const size_t elems = (size_t)n * n * 9;
+  SC_TRY(sc_reserve_scratch(ctx, elems * 8 + (size_t)k * 24 + (size_t)n * 24 + 4096));
+  Bump bump{(char*)ctx->scratch};
+  double* d_m = bump.take<double>(elems);
+  double* d_coord = bump.take<double>((size_t)n * 3);
+  int64_t* d_pairs = bump.take<int64_t>((size_t)k * 2 + 2);
+  double* d_g = bump.take<double>((size_t)k + 1);
+  SC_HIP(ctx, hipMemcpyAsync(d_coord, coord, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+  if (k > 0) {
+    SC_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, (size_t)k * 16, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_g, gamma, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SC_TRY(launch_hessian_from_pairs(ctx, d_coord, n, d_pairs, k, d_g, d_m));
+  SC_HIP(ctx, hipMemcpyAsync(hessian, d_m, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!a || !w))) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const size_t elems = (size_t)n * n;
+  SC_TRY(sc_reserve_scratch(ctx, elems * 8 * (v ? 2 : 1) + (size_t)n * 8 + 4096));
+  Bump bump{(char*)ctx->scratch};
+  double* d_a = bump.take<double>(elems);
+  double* d_w = bump.take<double>((size_t)n);
+  double* d_v = v ? bump.take<double>(elems) : nullptr;
+  SC_HIP(ctx, hipMemcpyAsync(d_a, a, elems * 8, hipMemcpyHostToDevice, ctx->stream));
+  SC_TRY(eigh_batched(ctx, d_a, n, 1, d_w, d_v));
+  SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+static int enm_eigen_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                          const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w,
+                          double* v, int dim) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  if (n > 0 && !w) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "w is NULL");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const int64_t m = n * dim;
+  const size_t elems = (size_t)m * m;
+  Staged st;
+  Bump bump{};
+  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass,
+                      elems * 8 * (v ? 2 : 1) + (size_t)m * 8 + 2048, st, bump));
+  double* d_m = bump.take<double>(elems);
+  double* d_w = bump.take<double>((size_t)m);
+  double* d_v = v ? bump.take<double>(elems) : nullptr;
+  const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
+  if (dim == 1)
+    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m, nullptr));
+  else
+    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m));
+  SC_TRY(eigh_batched(ctx, d_m, m, 1, d_w, d_v));
+  SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_anm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v) {
+  return enm_eigen_host(ctx, coord, n, ff, patch, inv_sqrt_mass, w, v, 3);
+}
+
+int sc_gnm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                     const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v) {
+  return enm_eigen_host(ctx, coord, n, ff, patch, inv_sqrt_mass, w, v, 1);
+}
+
+int sc_dev_kirchhoff_f64(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                         const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  SC_TRY(check_ff(ctx, ff));
+  if (n < 0 || batch < 0 || (n > 0 && batch > 0 && (!d_coord || !d_matrix)))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_kirchhoff(ctx, d_coord, n, batch, *ff, nullptr, d_inv_sqrt_mass, d_matrix, nullptr);
+}
+
+int sc_dev_hessian_f64(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                       const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  SC_TRY(check_ff(ctx, ff));
+  if (n < 0 || batch < 0 || (n > 0 && batch > 0 && (!d_coord || !d_matrix)))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_hessian(ctx, d_coord, n, batch, *ff, nullptr, d_inv_sqrt_mass, d_matrix);
+}
+
+int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || batch < 0 || (n > 0 && batch > 0 && (!d_a || !d_w)))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0 || batch == 0) return SC_OK;
+  return eigh_batched(ctx, d_a, n, batch, d_w, d_v);
+}
+
+int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors) {
+  if (n <= 0 || batch <= 0) return 0;
+  return (int64_t)eigh_workspace_bytes(n, batch, want_vectors != 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+// Contact scan + Kirchhoff / Hessian assembly kernels for gfx950 (MI355X).
+//
+// Replaces, on device, the reference's  _prepare_values_for_interaction_matrix
+// (interaction.py:114-190), compute_kirchhoff (interaction.py:14-54) and compute_hessian
+// (interaction.py:57-111).  HBM-write-bound O(N^2) work: 8 B per ordered atom pair for the
+// Kirchhoff matrix, 72 B per ordered pair for the Hessian.
+//
+// This translation unit is compiled with -ffp-contract=off: the contact predicate must
+// reproduce the reference's float64 arithmetic bit for bit,
+//     sq = (dx*dx + dy*dy) + dz*dz ;  contact = sq <= cutoff**2      (interaction.py:165-166)
+// with separately rounded products (no FMA).
+#include "common.h"
+
+namespace {
+
+struct FFDev {
+  int kind;
+  int has_cutoff;
+  double cutoff_sq;
+};
+
+__device__ __forceinline__ double ff_gamma(int kind, double d2) {
+  if (kind == SC_FF_INVARIANT) return 1.0;               // forcefield.py:284-285
+  if (kind == SC_FF_PARAMETER_FREE) return 1.0 / d2;     // forcefield.py:361-362
+  // Hinsen, forcefield.py:321-326
+  double d = sqrt(d2);
+  d = fmax(d, 2.9);
+  if (d < 4.0) return d * 8.6e2 - 2.39e3;
+  const double dd = d * d;
+  return 128e4 / (dd * dd * dd);  // d**-6 * 1.28e6, within 4 ulp of numpy's pow()
+}
+
+// Evaluates one ordered pair.  ci/cj are the coordinates; returns contact, fills d2, gamma, disp.
+template <bool PATCH>
+__device__ __forceinline__ bool pair_eval(int i, int j, double cix, double ciy, double ciz,
+                                          double cjx, double cjy, double cjz, const FFDev& ff,
+                                          const PatchDev& patch, int row_beg, int row_end,
+                                          bool shut_i, double& d2, double& gamma, double& dx,
+                                          double& dy, double& dz) {
+  dx = cjx - cix;
+  dy = cjy - ciy;
+  dz = cjz - ciz;
+  d2 = (dx * dx + dy * dy) + dz * dz;
+  const bool within = !ff.has_cutoff || (d2 <= ff.cutoff_sq);
+  bool contact = (i != j) && within;
+  gamma = 0.0;
+  if (PATCH) {
+    double gover = __builtin_nan("");
+    if (shut_i || patch.shut[j]) contact = false;  // interaction.py:201-203
+    for (int e = row_beg; e < row_end; ++e) {      // pair_off / pair_on, interaction.py:204-213
+      if (patch.col[e] == j) {
+        contact = patch.flag[e] != 0;
+        gover = patch.gam[e];
+      }
+    }
+    if (contact) {
+      // PatchedForceField.force_constant, forcefield.py:183-226
+      gamma = (patch.mask_gamma && !within) ? 0.0 : ff_gamma(ff.kind, d2);
+      if (gover == gover) gamma = gover;
+    }
+  } else {
+    if (contact) gamma = ff_gamma(ff.kind, d2);
+  }
+  return contact;
+}
+
+// Deterministic block-wide sum (256 threads = 4 waves): shuffle tree inside a wave, then a
+// fixed-order sum over the 4 wave results.  Result valid in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* red /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- Kirchhoff rows (+ contact counts) ---------------------------------------------------------
+// One block = TI consecutive atoms i (matrix rows) x all columns; thread = column j in a 256-wide
+// tile.  Row coordinates are wave-uniform registers, column coordinates are read once per tile and
+// reused for the TI rows.  Stores are 8 B per lane, contiguous along the row.
+template <int TI, bool PATCH>
+__global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ coord_all, int n,
+                                                   FFDev ff, PatchDev patch,
+                                                   const double* __restrict__ w_all,
+                                                   double* __restrict__ k_all,
+                                                   long long* __restrict__ counts_all) {
+  __shared__ double red[4];
+  const size_t b = blockIdx.y;
+  const double* coord = coord_all + b * (size_t)n * 3;
+  const double* w = w_all ? w_all + b * (size_t)n : nullptr;
+  double* K = k_all ? k_all + b * (size_t)n * n : nullptr;
+  long long* counts = counts_all ? counts_all + b * (size_t)n : nullptr;
+  const int i0 = blockIdx.x * TI;
+
+  double cix[TI], ciy[TI], ciz[TI], wi[TI];
+  int rbeg[TI], rend[TI];
+  bool shut[TI];
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    const int i = min(i0 + t, n - 1);
+    cix[t] = coord[3 * (size_t)i + 0];
+    ciy[t] = coord[3 * (size_t)i + 1];
+    ciz[t] = coord[3 * (size_t)i + 2];
+    wi[t] = w ? w[i] : 1.0;
+    rbeg[t] = rend[t] = 0;
+    shut[t] = false;
+    if (PATCH) {
+      rbeg[t] = patch.row_ptr[i];
+      rend[t] = patch.row_ptr[i + 1];
+      shut[t] = patch.shut[i] != 0;
+    }
+  }
+  double rsum[TI];
+  long long cnt[TI];
+#pragma unroll
+  for (int t = 0; t < TI; ++t) { rsum[t] = 0.0; cnt[t] = 0; }
+
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double cjx = coord[3 * (size_t)j + 0];
+    const double cjy = coord[3 * (size_t)j + 1];
+    const double cjz = coord[3 * (size_t)j + 2];
+    const double wj = w ? w[j] : 1.0;
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+      const int i = i0 + t;
+      if (i < n) {
+        double d2, g, dx, dy, dz;
+        const bool c = pair_eval<PATCH>(i, j, cix[t], ciy[t], ciz[t], cjx, cjy, cjz, ff, patch,
+                                        rbeg[t], rend[t], shut[t], d2, g, dx, dy, dz);
+        if (c) { rsum[t] += g; cnt[t] += 1; }
+        if (K && j != i) {
+          double v = c ? -g : 0.0;                     // interaction.py:50
+          if (w) v = v * (wi[t] * wj);                 // gnm.py:104-105
+          K[(size_t)i * n + j] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    const double s = block_sum_256(rsum[t], red);
+    const double c = block_sum_256((double)cnt[t], red);  // exact: counts < 2^53
+    const int i = i0 + t;
+    if (threadIdx.x == 0 && i < n) {
+      if (K) {
+        double v = s;                                  // -sum(-gamma), interaction.py:52
+        if (w) v = v * (wi[t] * wi[t]);
+        K[(size_t)i * n + i] = v;
+      }
+      if (counts) counts[i] = (long long)c;
+    }
+  }
+}
+
+// ---- Hessian rows ----------------------------------------------------------------------------------
+// One block = TI consecutive atoms i (3*TI matrix rows) x all columns.  Per 256-atom column tile each
+// thread evaluates ONE pair (i, j) -> its 3x3 block, parks it in LDS as three 768-double row segments
+// and the block then streams those segments out with fully contiguous 8-B-per-lane stores (a lane
+// writing its own 3 doubles would issue 24-B-strided partial-line stores).  Diagonal blocks are the
+// negated row sums, accumulated in registers and reduced in a fixed order (deterministic).
+template <int TI, bool PATCH>
+__global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coord_all, int n,
+                                                 FFDev ff, PatchDev patch,
+                                                 const double* __restrict__ w_all,
+                                                 double* __restrict__ h_all) {
+  __shared__ double tile[2][3][768];
+  __shared__ double red[4];
+  const size_t b = blockIdx.y;
+  const double* coord = coord_all + b * (size_t)n * 3;
+  const double* w = w_all ? w_all + b * (size_t)n : nullptr;
+  const size_t n3 = (size_t)n * 3;
+  double* H = h_all + b * n3 * n3;
+  const int i0 = blockIdx.x * TI;
+  const int tid = threadIdx.x;
+
+  double cix[TI], ciy[TI], ciz[TI], wi[TI];
+  int rbeg[TI], rend[TI];
+  bool shut[TI];
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    const int i = min(i0 + t, n - 1);
+    cix[t] = coord[3 * (size_t)i + 0];
+    ciy[t] = coord[3 * (size_t)i + 1];
+    ciz[t] = coord[3 * (size_t)i + 2];
+    wi[t] = w ? w[i] : 1.0;
+    rbeg[t] = rend[t] = 0;
+    shut[t] = false;
+    if (PATCH) {
+      rbeg[t] = patch.row_ptr[i];
+      rend[t] = patch.row_ptr[i + 1];
+      shut[t] = patch.shut[i] != 0;
+    }
+  }
+  double acc[TI][9];
+#pragma unroll
+  for (int t = 0; t < TI; ++t)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[t][q] = 0.0;
+
+  const int ntiles = (n + 255) / 256;
+  int buf = 0;
+  for (int tl = 0; tl < ntiles; ++tl) {
+    const int j = tl * 256 + tid;
+    const bool valid = j < n;
+    const int jc = valid ? j : n - 1;
+    const double cjx = coord[3 * (size_t)jc + 0];
+    const double cjy = coord[3 * (size_t)jc + 1];
+    const double cjz = coord[3 * (size_t)jc + 2];
+    const double wj = w ? w[jc] : 1.0;
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+      const int i = i0 + t;
+      if (i >= n) break;  // block-uniform
+      double blk[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) blk[q] = 0.0;
+      if (valid) {
+        double d2, g, dx, dy, dz;
+        const bool c = pair_eval<PATCH>(i, j, cix[t], ciy[t], ciz[t], cjx, cjy, cjz, ff, patch,
+                                        rbeg[t], rend[t], shut[t], d2, g, dx, dy, dz);
+        if (c) {
+          // interaction.py:96-101, left to right: ((-g / d2) * disp_a) * disp_b
+          const double tt = (-g) / d2;
+          const double d[3] = {dx, dy, dz};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double ta = tt * d[a];
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+              const double v = ta * d[bb];
+              acc[t][a * 3 + bb] += v;
+              blk[a * 3 + bb] = w ? v * (wi[t] * wj) : v;   // anm.py:112-113
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) tile[buf][a][3 * tid + bb] = blk[a * 3 + bb];
+      __syncthreads();
+      const size_t col0 = (size_t)tl * 768;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double* row = H + ((size_t)3 * i + a) * n3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = q * 256 + tid;
+          const size_t gc = col0 + c;
+          if (gc < n3 && (int)(gc / 3) != i) row[gc] = tile[buf][a][c];
+        }
+      }
+      buf ^= 1;
+    }
+  }
+  // diagonal blocks: H_ii = -sum_j B_ij  (interaction.py:103-104; B_ij == B_ji for symmetric gamma)
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    const int i = i0 + t;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const double s = block_sum_256(acc[t][q], red);
+      if (tid == 0 && i < n) {
+        double v = -s;
+        if (w) v = v * (wi[t] * wi[t]);
+        H[((size_t)3 * i + q / 3) * n3 + (size_t)3 * i + q % 3] = v;
+      }
+    }
+  }
+}
+
+// ---- ordered pair list (np.where order) ------------------------------------------------------------------
+// One wave per atom i; 64 candidate columns per step; ballot + prefix popcount gives each contact its
+// rank inside the row, so pairs come out sorted by (i, j) without atomics.
+template <bool PATCH>
+__global__ __launch_bounds__(256) void k_pair_fill(const double* __restrict__ coord, int n, FFDev ff,
+                                                   PatchDev patch,
+                                                   const long long* __restrict__ offsets,
+                                                   long long* __restrict__ pairs,
+                                                   double* __restrict__ sqd) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const double cix = coord[3 * (size_t)i + 0], ciy = coord[3 * (size_t)i + 1],
+               ciz = coord[3 * (size_t)i + 2];
+  int rbeg = 0, rend = 0;
+  bool shut = false;
+  if (PATCH) { rbeg = patch.row_ptr[i]; rend = patch.row_ptr[i + 1]; shut = patch.shut[i] != 0; }
+  long long base = offsets[i];
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    bool c = false;
+    double d2 = 0, g, dx, dy, dz;
+    if (j < n) {
+      const double cjx = coord[3 * (size_t)j + 0], cjy = coord[3 * (size_t)j + 1],
+                   cjz = coord[3 * (size_t)j + 2];
+      c = pair_eval<PATCH>(i, j, cix, ciy, ciz, cjx, cjy, cjz, ff, patch, rbeg, rend, shut, d2, g,
+                           dx, dy, dz);
+    }
+    const unsigned long long m = __ballot(c);
+    if (c) {
+      const long long r = base + __popcll(m & ((1ull << lane) - 1ull));
+      pairs[2 * r] = i;
+      pairs[2 * r + 1] = j;
+      if (sqd) sqd[r] = d2;
+    }
+    base += __popcll(m);
+  }
+}
+
+// ---- host-callback path: matrices from an explicit pair list + gamma[k] -----------------------------------
+__global__ void k_kirchhoff_scatter(int n, const long long* __restrict__ pairs, long long k,
+                                    const double* __restrict__ gamma, double* __restrict__ K) {
+  const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (p >= k) return;
+  const long long i = pairs[2 * p], j = pairs[2 * p + 1];
+  K[i * n + j] = -gamma[p];  // interaction.py:50
+}
+
+// diag_j = -sum_i K[i, j], accumulated sequentially over i exactly like np.sum(axis=0) (interaction.py:52)
+__global__ void k_kirchhoff_diag(int n, double* __restrict__ K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += K[(size_t)i * n + j];
+  K[(size_t)j * n + j] = -s;
+}
+
+__global__ void k_hessian_scatter(const double* __restrict__ coord, int n,
+                                  const long long* __restrict__ pairs, long long k,
+                                  const double* __restrict__ gamma, double* __restrict__ H) {
+  const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (p >= k) return;
+  const long long i = pairs[2 * p], j = pairs[2 * p + 1];
+  const double dx = coord[3 * j + 0] - coord[3 * i + 0];
+  const double dy = coord[3 * j + 1] - coord[3 * i + 1];
+  const double dz = coord[3 * j + 2] - coord[3 * i + 2];
+  const double d2 = (dx * dx + dy * dy) + dz * dz;
+  const double tt = (-gamma[p]) / d2;
+  const double d[3] = {dx, dy, dz};
+  const size_t n3 = (size_t)n * 3;
+  for (int a = 0; a < 3; ++a) {
+    const double ta = tt * d[a];
+    for (int b = 0; b < 3; ++b) H[(3 * i + a) * n3 + 3 * j + b] = ta * d[b];
+  }
+}
+
+// H4[i,i] = -sum_j' H4[j', i]: thread = (matrix column c = 3i+b, a); sequential over j' (np.sum axis 0).
+__global__ void k_hessian_diag(int n, double* __restrict__ H) {
+  const size_t n3 = (size_t)n * 3;
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= n3 * 3) return;
+  const size_t c = idx / 3;
+  const int a = (int)(idx % 3);
+  const size_t i = c / 3;
+  double s = 0.0;
+  for (int jp = 0; jp < n; ++jp) {
+    if ((size_t)jp == i) continue;  // the (i,i) block is still zero in the reference at this point
+    s += H[((size_t)3 * jp + a) * n3 + c];
+  }
+  H[(3 * i + a) * n3 + c] = -s;
+}
+
+FFDev make_ff(const sc_ff_desc& ff) { return FFDev{ff.kind, ff.has_cutoff, ff.cutoff_sq}; }
+
+}  // namespace
+
+int launch_kirchhoff(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                     const sc_ff_desc& ff, const PatchDev* patch, const double* d_w, double* d_k,
+                     int64_t* d_counts) {
+  if (n <= 0 || batch <= 0) return SC_OK;
+  constexpr int TI = 4;
+  dim3 grid((unsigned)((n + TI - 1) / TI), (unsigned)batch);
+  PatchDev p{};
+  if (patch) {
+    p = *patch;
+    hipLaunchKernelGGL((k_kirchhoff<TI, true>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_k, (long long*)d_counts);
+  } else {
+    hipLaunchKernelGGL((k_kirchhoff<TI, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_k, (long long*)d_counts);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int launch_contact_counts(sc_ctx* ctx, const double* d_coord, int64_t n, const sc_ff_desc& ff,
+                          const PatchDev* patch, int64_t* d_counts) {
+  return launch_kirchhoff(ctx, d_coord, n, 1, ff, patch, nullptr, nullptr, d_counts);
+}
+
+int launch_hessian(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                   const sc_ff_desc& ff, const PatchDev* patch, const double* d_w, double* d_h) {
+  if (n <= 0 || batch <= 0) return SC_OK;
+  constexpr int TI = 2;
+  dim3 grid((unsigned)((n + TI - 1) / TI), (unsigned)batch);
+  PatchDev p{};
+  if (patch) {
+    p = *patch;
+    hipLaunchKernelGGL((k_hessian<TI, true>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_h);
+  } else {
+    hipLaunchKernelGGL((k_hessian<TI, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_h);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int launch_pair_fill(sc_ctx* ctx, const double* d_coord, int64_t n, const sc_ff_desc& ff,
+                     const PatchDev* patch, const int64_t* d_offsets, int64_t* d_pairs,
+                     double* d_sqdist) {
+  if (n <= 0) return SC_OK;
+  dim3 grid((unsigned)((n + 3) / 4));
+  PatchDev p{};
+  if (patch) {
+    p = *patch;
+    hipLaunchKernelGGL((k_pair_fill<true>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, (const long long*)d_offsets, (long long*)d_pairs, d_sqdist);
+  } else {
+    hipLaunchKernelGGL((k_pair_fill<false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, (const long long*)d_offsets, (long long*)d_pairs, d_sqdist);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int launch_kirchhoff_from_pairs(sc_ctx* ctx, int64_t n, const int64_t* d_pairs, int64_t k,
+                                const double* d_gamma, double* d_k) {
+  SC_HIP(ctx, hipMemsetAsync(d_k, 0, sizeof(double) * (size_t)n * n, ctx->stream));
+  if (k > 0)
+    hipLaunchKernelGGL(k_kirchhoff_scatter, dim3((unsigned)((k + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (int)n, (const long long*)d_pairs, (long long)k, d_gamma, d_k);
+  hipLaunchKernelGGL(k_kirchhoff_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (int)n, d_k);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int launch_hessian_from_pairs(sc_ctx* ctx, const double* d_coord, int64_t n, const int64_t* d_pairs,
+                              int64_t k, const double* d_gamma, double* d_h) {
+  SC_HIP(ctx, hipMemsetAsync(d_h, 0, sizeof(double) * (size_t)n * n * 9, ctx->stream));
+  if (k > 0)
+    hipLaunchKernelGGL(k_hessian_scatter, dim3((unsigned)((k + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_coord, (int)n, (const long long*)d_pairs, (long long)k,
+                       d_gamma, d_h);
+  hipLaunchKernelGGL(k_hessian_diag, dim3((unsigned)((9 * n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, (int)n, d_h);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}

@@ -1,0 +1,91 @@
+// Internal declarations shared by the translation units of libspringcraft_hip.so.
+// Nothing here is part of the C ABI (see include/springcraft_hip.h for that).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/springcraft_hip.h"
+
+// ---- context -----------------------------------------------------------------------------
+struct sc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int num_cus = 0;
+
+  // cached device workspace for the eigensolver (grown on demand, never shrunk)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // small cached scratch for the assembly entry points (patch tables, counts, ...)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+
+  bool profiling = false;
+  double last_timings[6] = {0, 0, 0, 0, 0, 0};
+};
+
+int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);
+
+#define SC_HIP(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return sc_set_error((ctx), e__ == hipErrorOutOfMemory ? SC_ERR_NOMEM : SC_ERR_HIP, \
+                          "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),      \
+                          __FILE__, __LINE__);                                         \
+  } while (0)
+
+#define SC_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != SC_OK) return rc__; \
+  } while (0)
+
+// Grow-only cached allocations.
+int sc_reserve_ws(sc_ctx* ctx, size_t bytes);
+int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- assembly (assembly.hip) ----------------------------------------------------------------
+// Device-side patch tables (all device pointers; null when there are no patches).
+struct PatchDev {
+  const uint8_t* shut;     // (N) 1 = every contact of this atom is switched off
+  const int32_t* row_ptr;  // (N+1) CSR over override entries, both directions stored
+  const int32_t* col;      // (nnz)
+  const int8_t* flag;      // (nnz) 0 = force off, 1 = force on
+  const double* gam;       // (nnz) override force constant, NaN = use the base force field
+  int mask_gamma;          // PatchedForceField: base gamma is 0 beyond the base cutoff
+};
+
+int launch_kirchhoff(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                     const sc_ff_desc& ff, const PatchDev* patch, const double* d_w,
+                     double* d_k, int64_t* d_counts);
+int launch_hessian(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
+                   const sc_ff_desc& ff, const PatchDev* patch, const double* d_w, double* d_h);
+int launch_contact_counts(sc_ctx* ctx, const double* d_coord, int64_t n, const sc_ff_desc& ff,
+                          const PatchDev* patch, int64_t* d_counts);
+// d_offsets: exclusive scan of counts (N+1 entries, last = k)
+int launch_pair_fill(sc_ctx* ctx, const double* d_coord, int64_t n, const sc_ff_desc& ff,
+                     const PatchDev* patch, const int64_t* d_offsets, int64_t* d_pairs,
+                     double* d_sqdist);
+int launch_exclusive_scan_i64(sc_ctx* ctx, const int64_t* d_in, int64_t n, int64_t* d_out);
+int launch_kirchhoff_from_pairs(sc_ctx* ctx, int64_t n, const int64_t* d_pairs, int64_t k,
+                                const double* d_gamma, double* d_k);
+int launch_hessian_from_pairs(sc_ctx* ctx, const double* d_coord, int64_t n,
+                              const int64_t* d_pairs, int64_t k, const double* d_gamma,
+                              double* d_h);
+// In-place transpose-free symmetric "row-major == column-major" note: the eigensolver reads the
+// LOWER triangle in column-major order, i.e. the UPPER triangle of the row-major matrix the
+// assembly writes; the matrices are symmetric so both views agree.
+
+// ---- eigensolver (eigh.hip and friends) ----------------------------------------------------
+// d_a: (batch, n, n) symmetric (destroyed), d_w: (batch, n), d_v: nullptr or (batch, n, n) rows = modes.
+int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
+size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors);

@@ -1,0 +1,37 @@
+// Grouped / batched float64 GEMM on the gfx950 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//     C[i,j] = beta * C[i,j] + alpha * sum_k A(i,k) * B(k,j)          (column-major C, ldc)
+//
+// A(i,k) = a[i*sa_i + k*sa_k + (a_kidx ? a_kidx[k]*sa_k ... see below)], B(k,j) = b[k*sb_k + j*sb_j]:
+// arbitrary strides, so NN / NT / TN products and sub-matrix views need no copies.  One of
+// (sa_i, sa_k) and one of (sb_k, sb_j) must be 1 (the loader runs its lanes along that axis).
+//
+// Problems are described by GemmDesc records in DEVICE memory, so sizes may be produced by a
+// previous kernel (the divide & conquer merges: the number of non-deflated eigenvalues is only
+// known on the device).  blockIdx.z selects the record; blocks outside m x n exit at once.
+#pragma once
+
+#include <cstdint>
+
+#include "common.h"
+
+struct GemmDesc {
+  const double* a;
+  const double* b;
+  double* c;
+  int m, n, k;
+  long long sa_i, sa_k;   // element strides of A(i,k)
+  long long sb_k, sb_j;   // element strides of B(k,j)
+  long long ldc;          // column stride of C (row stride is 1)
+  double alpha, beta;
+  const int* a_kidx;      // optional gather on A's k axis: A(i,k) = a[i*sa_i + a_kidx[k]*sa_k]
+  const int* c_jidx;      // optional scatter on C's column axis: C(:, j) lives at column c_jidx[j]
+  int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K)
+  int row_off, col_off;
+  int split_k;            // >1: blockIdx.z % split_k selects a K slice; slice s writes C + s*split_stride (beta ignored)
+  long long split_stride;
+};
+
+// Launch `count` problems (records d_desc[0..count)); max_m / max_n bound the grid.
+// tile: 0 = 128x128 block tile, 1 = 64x128 (short-and-wide products).
+int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile);

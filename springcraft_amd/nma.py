@@ -1,0 +1,177 @@
+"""
+Normal-mode analysis on top of the device eigensolver.
+
+``eigen`` is the hot-path function (reference: nma.py:29-63): a dense symmetric float64
+eigendecomposition, here performed by the hand-written HIP solver (``csrc/eigh*.hip``) instead
+of LAPACK ``dsyevd``.  The remaining functions are thin NumPy consumers of its output
+(reference: nma.py:66-569); they are outside the accelerated path and kept so that analyses
+written against springcraft keep working.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+
+__all__ = [
+    "eigen", "eigh", "frequencies", "mean_square_fluctuation", "bfactor", "dcc",
+    "normal_mode", "linear_response", "prs", "effector_sensor",
+]
+
+K_B = 1.380649e-23
+N_A = 6.02214076e23
+
+
+def eigh(matrix, eigenvectors=True):
+    """
+    Device replacement for ``np.linalg.eigh(matrix)`` as used at nma.py:61: ascending
+    eigenvalues of a symmetric float64 matrix (lower triangle read) and, as ROWS, the
+    corresponding eigenvectors (``eig_vectors[i]`` belongs to ``eig_values[i]``).
+    """
+    a = np.ascontiguousarray(matrix, dtype=np.float64)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError(f"Expected a square matrix, got shape {a.shape}")
+    n = a.shape[0]
+    ctx = _hip.context()
+    w = np.empty(n, dtype=np.float64)
+    v = np.empty((n, n), dtype=np.float64) if eigenvectors else None
+    ctx.check(_hip.lib().sc_eigh_f64(ctx.handle, _hip.ptr(a), n, _hip.ptr(w), _hip.ptr(v)))
+    return (w, v) if eigenvectors else w
+
+
+def _model_kind(enm):
+    from .anm import ANM
+    from .gnm import GNM
+
+    if isinstance(enm, GNM):
+        return "gnm", 1
+    if isinstance(enm, ANM):
+        return "anm", 6
+    raise ValueError("Instance of GNM/ANM class expected.")
+
+
+def eigen(enm):
+    """
+    Eigenvalues (ascending) and eigenvectors (rows) of the Kirchhoff / Hessian matrix of a
+    GNM / ANM (reference: nma.py:29-63).
+    """
+    _model_kind(enm)
+    return enm._eigen_device()
+
+
+def frequencies(enm):
+    """Frequencies sqrt(lambda)/(2 pi) of all modes; trivial eigenvalues enter as |lambda| (nma.py:66-105)."""
+    _, ntriv = _model_kind(enm)
+    w, _ = eigen(enm)
+    w = np.array(w)
+    w[:ntriv] = np.abs(w[:ntriv])
+    return np.sqrt(w) / (2 * np.pi)
+
+
+def _mode_selection(enm, mode_subset, n_modes):
+    _, ntriv = _model_kind(enm)
+    if mode_subset is None:
+        return np.arange(ntriv, n_modes)
+    subset = np.asarray(mode_subset)
+    if np.any(subset < ntriv):
+        raise ValueError("Trivial modes are included in the current selection. Please check your input.")
+    return subset
+
+
+def mean_square_fluctuation(enm, mode_subset=None, tem=None, tem_factors=K_B):
+    """Per-atom mean square fluctuation sum_k v_k^2 / lambda_k over the selected modes (nma.py:108-184)."""
+    kind, _ = _model_kind(enm)
+    w, v = eigen(enm)
+    sel = _mode_selection(enm, mode_subset, len(w))
+    contrib = (v[sel] ** 2 / w[sel, None]).sum(axis=0)
+    if kind == "anm":
+        contrib = contrib.reshape(-1, 3).sum(axis=1)
+    if tem is not None:
+        contrib = contrib * (tem * tem_factors)
+    return contrib
+
+
+def bfactor(enm, mode_subset=None, tem=None, tem_factors=K_B):
+    """Isotropic B-factors 8 pi^2/3 x MSF (nma.py:187-230)."""
+    return (8 * np.pi**2) / 3 * mean_square_fluctuation(enm, mode_subset, tem, tem_factors)
+
+
+def dcc(enm, mode_subset=None, norm=True, tem=None, tem_factors=K_B):
+    """Dynamic cross-correlation between nodes over the selected modes (nma.py:233-359)."""
+    kind, _ = _model_kind(enm)
+    w, v = eigen(enm)
+    sel = _mode_selection(enm, mode_subset, len(w))
+    vs = v[sel]
+    cov = (vs.T / w[sel]) @ vs  # sum_k v_k v_k^T / lambda_k
+    if kind == "anm":
+        n = cov.shape[0] // 3
+        cov = cov.reshape(n, 3, n, 3).trace(axis1=1, axis2=3)
+    if norm:
+        d = np.sqrt(np.diag(cov))
+        cov = cov / np.outer(d, d)
+    if tem is not None:  # applied after the normalisation, as the reference does (nma.py:355-357)
+        cov = cov * tem * tem_factors
+    return cov
+
+
+def normal_mode(anm, index, amplitude, frames, movement="sine"):
+    """Displacement trajectory (frames, n, 3) for one oscillation of mode ``index`` (nma.py:363-419)."""
+    from .anm import ANM
+
+    if not isinstance(anm, ANM):
+        raise ValueError("Instance of ANM class expected.")
+    _, v = eigen(anm)
+    mode = v[index].reshape(-1, 3)
+    mode = mode * (amplitude / np.sqrt((mode**2).sum(axis=-1)).max())
+    phase = np.linspace(0, 1, frames, endpoint=False)
+    if movement == "sine":
+        scale = np.sin(phase * 2 * np.pi)
+    elif movement == "triangle":
+        # triangle wave from -1 (phase 0) over +1 (phase 1/2) back to -1 (nma.py:413)
+        scale = 2 * np.abs(2 * (phase - np.floor(phase + 0.5))) - 1
+    else:
+        raise ValueError(f"Movement '{movement}' is unknown")
+    return scale[:, None, None] * mode[None, :, :]
+
+
+def linear_response(anm, force):
+    """Linear-response displacement covariance . force, reshaped to (n,3) (nma.py:422-473)."""
+    from .anm import ANM
+
+    if not isinstance(anm, ANM):
+        raise ValueError("Instance of ANM class expected.")
+    force = np.asarray(force)
+    n3 = anm.covariance.shape[0]
+    if force.ndim == 2:
+        if force.shape != (n3 // 3, 3):
+            raise ValueError(f"Expected force with shape {(n3 // 3, 3)}, got {force.shape}")
+        force = force.ravel()
+    elif force.ndim == 1:
+        if len(force) != n3:
+            raise ValueError(f"Expected force with length {n3}, got {len(force)}")
+    else:
+        raise ValueError(f"Expected 1D or 2D array, got {force.ndim} dimensions")
+    return (anm.covariance @ force).reshape(-1, 3)
+
+
+def prs(anm, norm=True):
+    """Perturbation-response-scanning matrix from the squared covariance (nma.py:476-524)."""
+    from .anm import ANM
+
+    if not isinstance(anm, ANM):
+        raise ValueError("Instance of ANM class expected.")
+    c2 = anm.covariance**2
+    n = c2.shape[0] // 3
+    mat = c2.reshape(n, 3, n, 3).sum(axis=(1, 3))
+    if norm:
+        mat = mat / np.diag(mat)[:, None]
+    return mat
+
+
+def effector_sensor(prs_matrix):
+    """Row / column means of the off-diagonal PRS entries (nma.py:527-569)."""
+    m = np.array(prs_matrix, dtype=float)
+    n = len(m)
+    off = m - np.diag(np.diag(m))
+    return off.sum(axis=1) / (n - 1), off.sum(axis=0) / (n - 1)
