@@ -1,0 +1,208 @@
+// Driver of the batched dense symmetric eigensolver (replaces np.linalg.eigh at the reference's
+// nma.py:61): mirror -> tridiagonalise (tridiag.hip) -> tridiagonal eigenproblem (stedc.hip, or Sturm
+// bisection when only eigenvalues are wanted) -> back-transformation (backtransform.hip).
+// Also owns the workspace layout: everything the stages need is carved out of ONE cached device
+// allocation per context (sc_ctx::ws), sized by eigh_workspace_bytes().
+#include <algorithm>
+#include <vector>
+
+#include "eigh_internal.h"
+
+namespace {
+
+constexpr int kNb = 64;  // tridiagonalisation panel width (SYR2K inner dimension = 2 * kNb)
+
+size_t tri_slab_doubles(int n, TriLayout* out) {
+  TriLayout L{};
+  L.n = n;
+  L.nb = kNb;
+  const long long nt = (n + 63) / 64 + 1;
+  long long off = 0;
+  auto take = [&](long long cnt) { long long o = off; off += (cnt + 7) / 8 * 8; return o; };
+  L.vw = take((long long)n * 2 * kNb);
+  L.wv = take((long long)n * 2 * kNb);
+  L.xraw = take(n);
+  L.ypart = take(nt * n);
+  L.dpart = take(nt * 2 * kNb);
+  L.npart = take(n / 256 + 8);
+  L.wvpart = take(n / 256 + 8);
+  L.d = take(n);
+  L.e = take(n);
+  L.tau = take(n);
+  L.slab = off;
+  if (out) *out = L;
+  return (size_t)off;
+}
+
+struct Plan {
+  TriLayout TL;
+  DcLayout DL;
+  BtLayout BL;
+  size_t off_tri = 0, off_dc = 0, off_bt = 0, off_qtmp = 0, off_u = 0, off_desc = 0, total = 0;
+  int n_syr2k = 0, n_merge = 0, n_bt = 0;
+};
+
+Plan make_plan(int n, int batch, bool vectors) {
+  Plan P;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  P.off_tri = take(tri_slab_doubles(n, &P.TL) * 8 * batch);
+  const int npanels = (n + kNb - 1) / kNb;
+  P.n_syr2k = npanels * batch;
+  if (vectors) {
+    P.off_dc = take(dc_slab_doubles(n, &P.DL) * 8 * batch);
+    P.off_bt = take(bt_slab_doubles(n, &P.BL) * 8 * batch);
+    P.off_qtmp = take((size_t)n * n * 8 * batch);
+    P.off_u = take((size_t)n * n * 8 * batch);
+    P.n_merge = dc_max_nodes(n, P.DL.leaf_max) * batch;
+    const int nref = n - 2 > 0 ? n - 2 : 0;
+    P.n_bt = ((nref + P.BL.nbt - 1) / P.BL.nbt) * 3 * batch;
+  }
+  P.off_desc = take(sizeof(GemmDesc) * ((size_t)P.n_syr2k + P.n_merge + P.n_bt + 8));
+  P.total = off;
+  return P;
+}
+
+// ---- eigenvalues only: Sturm bisection, one thread per eigenvalue ------------------------------------------
+__global__ __launch_bounds__(256) void k_sturm(const double* __restrict__ tri_all, TriLayout TL,
+                                               double* __restrict__ w_all, long long stride_w) {
+  const double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  const double* d = tri + TL.d;
+  const double* e = tri + TL.e;
+  const int n = TL.n;
+  __shared__ double red[8];
+  // Gershgorin bounds + pivmin (block-wide)
+  double lo = 1e300, hi = -1e300, emax = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i < n - 1 ? fabs(e[i]) : 0.0;
+    lo = fmin(lo, d[i] - el - er);
+    hi = fmax(hi, d[i] + el + er);
+    emax = fmax(emax, er);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, off));
+    hi = fmax(hi, __shfl_xor(hi, off));
+    emax = fmax(emax, __shfl_xor(emax, off));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w] = lo; red[4 + w] = hi; }
+  __syncthreads();
+  lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+  hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = emax;
+  __syncthreads();
+  emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double span = fmax(fabs(lo), fabs(hi));
+  const double pivmin = fmax(2.2250738585072014e-308 * fmax(1.0, emax * emax), 1e-290);
+  lo -= 2.0 * 2.2e-16 * span * n + 2.0 * pivmin;
+  hi += 2.0 * 2.2e-16 * span * n + 2.0 * pivmin;
+
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // eigenvalue index (ascending)
+  if (k >= n) return;
+  double a = lo, b = hi;
+  for (int it = 0; it < 120; ++it) {
+    const double mid = 0.5 * (a + b);
+    if (mid <= a || mid >= b) break;
+    int cnt = 0;
+    double q = d[0] - mid;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.0;
+    for (int i = 1; i < n; ++i) {
+      const double ee = e[i - 1];
+      q = d[i] - mid - ee * ee / q;
+      if (fabs(q) < pivmin) q = -pivmin;
+      cnt += q < 0.0;
+    }
+    if (cnt > k) b = mid; else a = mid;
+  }
+  w_all[(size_t)blockIdx.y * stride_w + k] = 0.5 * (a + b);
+}
+
+}  // namespace
+
+int sturm_bisect_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const TriLayout& TL,
+                         double* d_w, long long stride_w) {
+  hipLaunchKernelGGL(k_sturm, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, ctx->stream,
+                     d_tri_ws, TL, d_w, stride_w);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors) {
+  return make_plan((int)n, (int)batch, want_vectors).total;
+}
+
+int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double* d_w, double* d_v) {
+  if (n64 > 46000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "matrix order %lld too large", (long long)n64);
+  const int n = (int)n64, batch = (int)batch64;
+  const bool vectors = d_v != nullptr;
+  hipStream_t st = ctx->stream;
+  const Plan P = make_plan(n, batch, vectors);
+  SC_TRY(sc_reserve_ws(ctx, P.total));
+  char* base = (char*)ctx->ws;
+  double* tri_ws = (double*)(base + P.off_tri);
+  GemmDesc* descs = (GemmDesc*)(base + P.off_desc);
+  const long long stride_a = (long long)n * n;
+
+  // SYR2K descriptors: one per (panel, matrix)
+  const int npanels = (n + kNb - 1) / kNb;
+  std::vector<GemmDesc> h((size_t)npanels * batch);
+  for (int p = 0; p < npanels; ++p) {
+    const int pend = std::min((p + 1) * kNb, n);
+    for (int b = 0; b < batch; ++b) {
+      double* ws = tri_ws + (size_t)b * P.TL.slab;
+      GemmDesc D{};
+      D.a = ws + P.TL.vw + pend; D.sa_i = 1; D.sa_k = n;
+      D.b = ws + P.TL.wv + pend; D.sb_k = n; D.sb_j = 1;
+      D.c = d_a + (size_t)b * stride_a + (size_t)pend * n + pend; D.ldc = n;
+      D.m = n - pend; D.n = n - pend; D.k = 2 * kNb;
+      D.alpha = -1.0; D.beta = 1.0;
+      D.lower_only = 1;
+      h[(size_t)p * batch + b] = D;
+    }
+  }
+  SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  const bool prof = ctx->profiling;
+  if (prof) {
+    for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
+    SC_HIP(ctx, hipEventRecord(ev[0], st));
+  }
+  float ms_symv = 0.f, ms_syr2k = 0.f;
+  SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, descs, &ms_symv, &ms_syr2k));
+  if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
+
+  if (!vectors) {
+    SC_TRY(sturm_bisect_batched(ctx, n, batch, tri_ws, P.TL, d_w, n));
+    if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
+  } else {
+    double* dc_ws = (double*)(base + P.off_dc);
+    double* bt_ws = (double*)(base + P.off_bt);
+    double* q_tmp = (double*)(base + P.off_qtmp);
+    double* u = (double*)(base + P.off_u);
+    SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
+                         descs + P.n_syr2k));
+    if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
+    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a,
+                                 descs + P.n_syr2k + P.n_merge));
+  }
+  if (prof) {
+    SC_HIP(ctx, hipEventRecord(ev[3], st));
+    SC_HIP(ctx, hipEventSynchronize(ev[3]));
+    float t01 = 0, t12 = 0, t23 = 0;
+    SC_HIP(ctx, hipEventElapsedTime(&t01, ev[0], ev[1]));
+    SC_HIP(ctx, hipEventElapsedTime(&t12, ev[1], ev[2]));
+    SC_HIP(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
+    ctx->last_timings[0] = t01;
+    ctx->last_timings[1] = t12;
+    ctx->last_timings[2] = t23;
+    ctx->last_timings[3] = ms_symv;
+    ctx->last_timings[4] = ms_syr2k;
+    ctx->last_timings[5] = 0.0;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads
+  return SC_OK;
+}

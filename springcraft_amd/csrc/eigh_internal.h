@@ -1,0 +1,84 @@
+// Internal interfaces between the stages of the batched symmetric eigensolver
+//   tridiag.hip (K5)  ->  stedc.hip (K6)  ->  backtransform.hip (K7),  driven by eigh.hip.
+#pragma once
+
+#include "common.h"
+#include "gemm_f64.h"
+
+// Per-matrix workspace slab of the tridiagonalisation (offsets in doubles from the slab base).
+struct TriLayout {
+  int n, nb;
+  long long slab;    // slab stride between consecutive matrices of the batch
+  long long vw;      // [V|W] panel, n x 2nb, column-major ld n
+  long long wv;      // [W|V] panel, n x 2nb
+  long long xraw;    // updated column a (n)
+  long long ypart;   // SYMV partial products, nt x n
+  long long dpart;   // partial dots V^T v / W^T v, nt x 2nb
+  long long npart;   // partial squared norms (<= n/256 + 1)
+  long long wvpart;  // partial w~^T v
+  long long d, e, tau;  // tridiagonal + reflector scalars (n each)
+};
+
+// d_a: (batch) n x n column-major, lower triangle valid after the mirror pass; on exit column c holds
+// v_c (explicit leading 1) in rows c+1.., and ws holds d, e, tau.
+int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
+                    const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv, float* ms_syr2k);
+
+// ---- divide & conquer ------------------------------------------------------------------------------
+struct DcNode {
+  int lo, mid, hi;
+};
+
+struct DcLayout {
+  int n;
+  int leaf_max;      // leaves have at most this many rows
+  long long slab;    // per-matrix stride (doubles) of the D&C slab
+  long long dd, ee;  // scaled copies of d, e (n each)
+  long long w0, w1;  // eigenvalue ping-pong (n each)
+  long long z;       // rank-one vector (n)
+  long long dl, zz;  // non-deflated poles / weights, compacted per node at [lo, lo+K)
+  long long ddef;    // deflated eigenvalues per node at [lo, lo+ndef)
+  long long lam;     // new roots per node (n)
+  long long tauv;    // secular root offsets (n)
+  long long zhat;    // Gu-Eisenstat weights (n)
+  long long rot_c, rot_s;  // rotation list (n each)
+  long long scale;   // [0] = norm used for scaling
+  // integer arrays live in the same slab, offsets in doubles (each int array padded to n doubles)
+  long long src;     // int[n]: source column of non-deflated k (at lo+k); of deflated e (at lo+K+e)
+  long long org;     // int[n]: origin pole of each root
+  long long dest;    // int[n]: destination column of non-deflated k (at lo+k) / deflated (at lo+K+e)
+  long long rot_a, rot_b;  // int[n] each: rotated column pairs
+  long long cnt;     // int[2 * max_nodes]: per node K and number of rotations
+};
+
+// Eigen-decomposition of `batch` symmetric tridiagonal matrices (d, e in the TriLayout slab).
+// On exit: d_w (batch, n) ascending eigenvalues; eigenvectors (columns) in d_q_out (batch, n, n).
+// d_q_tmp / d_u: two more (batch, n, n) work matrices.
+int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const TriLayout& TL,
+                  double* d_dc_ws, const DcLayout& DL, double* d_w, long long stride_w,
+                  double* d_q_out, double* d_q_tmp, double* d_u, long long stride_q,
+                  GemmDesc* d_merge_descs /* max_nodes_per_level * batch */);
+size_t dc_slab_doubles(int n, DcLayout* out);
+int dc_max_nodes(int n, int leaf_max);
+
+// Eigenvalues only: Sturm-sequence bisection (one thread per eigenvalue).
+int sturm_bisect_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const TriLayout& TL,
+                         double* d_w, long long stride_w);
+
+// ---- back-transformation -----------------------------------------------------------------------------
+// Z <- Q_H Z with the reflectors stored in d_a (see tridiag_batched) and tau in the tri slab.
+struct BtLayout {
+  int n, nbt, splits;
+  long long slab;
+  long long vc;     // clean panel copy, n x nbt
+  long long gram;   // split-K slabs of V^T V: splits_g x nbt x nbt
+  long long t;      // nbt x nbt triangular factor
+  long long w1;     // split-K slabs of V^T Z: splits x nbt x n
+  long long w2;     // T * sum(w1): nbt x n
+  int splits_g;
+};
+size_t bt_slab_doubles(int n, BtLayout* out);
+int backtransform_batched(sc_ctx* ctx, const double* d_a, long long stride_a, int n, int batch,
+                          const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws,
+                          const BtLayout& BL, double* d_z, long long stride_z,
+                          GemmDesc* d_descs /* 3 * batch scratch records */);

@@ -28,10 +28,11 @@ struct GemmDesc {
   const int* c_jidx;      // optional scatter on C's column axis: C(:, j) lives at column c_jidx[j]
   int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K)
   int row_off, col_off;
-  int split_k;            // >1: blockIdx.z % split_k selects a K slice; slice s writes C + s*split_stride (beta ignored)
-  long long split_stride;
+  long long split_stride; // split-K launches: slice s writes alpha*partial to C + s*split_stride (beta ignored)
 };
 
 // Launch `count` problems (records d_desc[0..count)); max_m / max_n bound the grid.
 // tile: 0 = 128x128 block tile, 1 = 64x128 (short-and-wide products).
-int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile);
+// split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
+int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
+                    int split_k = 1);

@@ -1,0 +1,219 @@
+// float64 GEMM on the CDNA4 matrix cores — see gemm_f64.h for the contract.
+//
+// Block tile BM x 128 (BM = 128 or 64), K step 16, 256 threads = 4 waves arranged 2 x 2, each wave
+// owning a (BM/2) x 64 sub-tile built from v_mfma_f64_16x16x4_f64 tiles (64 lanes x 4 f64 results).
+// Two blocks per CU = 2 waves per SIMD, >= 8 independent accumulators per wave: the regime in which
+// the f64 MFMA pipe reached its practical ceiling in profiles/r01_probe_f64.txt (47 TFLOP/s).
+//
+// Operand staging: global -> registers (next K step, issued before the MFMAs of the current step)
+// -> LDS [k][m|n] double-buffered, one barrier per K step.  LDS rows are padded to tile+16 doubles
+// so the four k-rows a ds_read_b64 wave-instruction touches fall on disjoint banks.
+//
+// The MFMA is fed "swapped" (its A operand comes from the B tile, its B operand from the A tile):
+// the accumulator then holds C^T fragments whose 16 consecutive lanes map to 16 consecutive ROWS
+// of the column-major C, so C loads / stores are 128-byte contiguous segments.
+#include "gemm_f64.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr int BN = 128;
+constexpr int PAD = 16;
+
+template <int BM>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+  constexpr int A_PER_THREAD = BM * BK / 256, B_PER_THREAD = BN * BK / 256;
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sA = smem;                        // [2][BK][LDA_S]
+  double* sB = smem + 2 * BK * LDA_S;       // [2][BK][LDB_S]
+
+  const int z = blockIdx.z;
+  const int slice = split_k > 1 ? z % split_k : 0;
+  const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
+  const int M = D.m, N = D.n, K = D.k;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M || n0 >= N || K <= 0) return;
+  if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
+
+  int k_begin = 0, k_end = K;
+  if (split_k > 1) {
+    const int chunk = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
+    k_begin = slice * chunk;
+    k_end = min(K, k_begin + chunk);
+  }
+
+  const double* __restrict__ A = D.a;
+  const double* __restrict__ B = D.b;
+  const long long sa_i = D.sa_i, sa_k = D.sa_k, sb_k = D.sb_k, sb_j = D.sb_j;
+  const int* __restrict__ kidx = D.a_kidx;
+  const bool a_mcontig = (sa_i == 1);
+  const bool b_ncontig = (sb_j == 1);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  double ra[A_PER_THREAD], rb[B_PER_THREAD];
+
+  auto load_tiles = [&](int kt) {
+    // A tile: BM x BK
+    if (a_mcontig) {
+      const int i = tid % BM, kq = tid / BM;
+      constexpr int KSTEP = 256 / BM;
+#pragma unroll
+      for (int p = 0; p < A_PER_THREAD; ++p) {
+        const int k = kt + kq + p * KSTEP;
+        const int gi = m0 + i;
+        double v = 0.0;
+        if (gi < M && k < k_end) {
+          const long long kk = kidx ? (long long)kidx[k] : (long long)k;
+          v = A[(long long)gi + kk * sa_k];
+        }
+        ra[p] = v;
+      }
+    } else {
+      const int k = tid % BK, iq = tid / BK;
+      constexpr int ISTEP = 256 / BK;
+#pragma unroll
+      for (int p = 0; p < A_PER_THREAD; ++p) {
+        const int gi = m0 + iq + p * ISTEP;
+        const int gk = kt + k;
+        ra[p] = (gi < M && gk < k_end) ? A[(long long)gi * sa_i + gk] : 0.0;
+      }
+    }
+    // B tile: BK x BN
+    if (b_ncontig) {
+      const int j = tid % BN, kq = tid / BN;
+      constexpr int KSTEP = 256 / BN;
+#pragma unroll
+      for (int p = 0; p < B_PER_THREAD; ++p) {
+        const int k = kt + kq + p * KSTEP;
+        const int gj = n0 + j;
+        rb[p] = (gj < N && k < k_end) ? B[(long long)k * sb_k + gj] : 0.0;
+      }
+    } else {
+      const int k = tid % BK, jq = tid / BK;
+      constexpr int JSTEP = 256 / BK;
+#pragma unroll
+      for (int p = 0; p < B_PER_THREAD; ++p) {
+        const int gj = n0 + jq + p * JSTEP;
+        const int gk = kt + k;
+        rb[p] = (gj < N && gk < k_end) ? B[(long long)gk + (long long)gj * sb_j] : 0.0;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    double* a_s = sA + buf * BK * LDA_S;
+    double* b_s = sB + buf * BK * LDB_S;
+    if (a_mcontig) {
+      const int i = tid % BM, kq = tid / BM;
+      constexpr int KSTEP = 256 / BM;
+#pragma unroll
+      for (int p = 0; p < A_PER_THREAD; ++p) a_s[(kq + p * KSTEP) * LDA_S + i] = ra[p];
+    } else {
+      const int k = tid % BK, iq = tid / BK;
+      constexpr int ISTEP = 256 / BK;
+#pragma unroll
+      for (int p = 0; p < A_PER_THREAD; ++p) a_s[k * LDA_S + iq + p * ISTEP] = ra[p];
+    }
+    if (b_ncontig) {
+      const int j = tid % BN, kq = tid / BN;
+      constexpr int KSTEP = 256 / BN;
+#pragma unroll
+      for (int p = 0; p < B_PER_THREAD; ++p) b_s[(kq + p * KSTEP) * LDB_S + j] = rb[p];
+    } else {
+      const int k = tid % BK, jq = tid / BK;
+      constexpr int JSTEP = 256 / BK;
+#pragma unroll
+      for (int p = 0; p < B_PER_THREAD; ++p) b_s[k * LDB_S + jq + p * JSTEP] = rb[p];
+    }
+  };
+
+  d4 acc[NT][MT];
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int fr = lane & 15, fk = lane >> 4;
+
+  load_tiles(k_begin);
+  store_tiles(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = k_begin; kt < k_end; kt += BK) {
+    const bool has_next = kt + BK < k_end;
+    if (has_next) load_tiles(kt + BK);
+    const double* a_s = sA + buf * BK * LDA_S;
+    const double* b_s = sB + buf * BK * LDB_S;
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) {
+      double af[MT], bf[NT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[mi] = a_s[(k4 * 4 + fk) * LDA_S + wm * WM + mi * 16 + fr];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bf[ni] = b_s[(k4 * 4 + fk) * LDB_S + wn * WN + ni * 16 + fr];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (has_next) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: acc[ni][mi][r] = C(row = m0 + wm*WM + mi*16 + fr, col = n0 + wn*WN + ni*16 + fk + 4r)
+  double* __restrict__ C = D.c + (split_k > 1 ? (long long)slice * D.split_stride : 0LL);
+  const double alpha = D.alpha;
+  const double beta = split_k > 1 ? 0.0 : D.beta;
+  const long long ldc = D.ldc;
+  const int* __restrict__ jidx = D.c_jidx;
+  const bool lower = D.lower_only != 0;
+  const int roff = D.row_off, coff = D.col_off;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
+      if (col >= N) continue;
+      const long long dcol = jidx ? (long long)jidx[col] : (long long)col;
+      double* ccol = C + dcol * ldc;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int row = m0 + wm * WM + mi * 16 + fr;
+        if (row >= M) continue;
+        if (lower && (row + roff) < (col + coff)) continue;
+        double v = alpha * acc[ni][mi][r];
+        if (beta != 0.0) v += beta * ccol[row];
+        ccol[row] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
+                    int split_k) {
+  if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
+  if (split_k < 1) split_k = 1;
+  const int bm = tile == 1 ? 64 : 128;
+  dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + BN - 1) / BN),
+            (unsigned)(count * split_k));
+  const size_t lds = sizeof(double) * 2 * BK * ((size_t)(bm + PAD) + (BN + PAD));
+  if (tile == 1)
+    hipLaunchKernelGGL(k_gemm_f64<64>, grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  else
+    hipLaunchKernelGGL(k_gemm_f64<128>, grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
