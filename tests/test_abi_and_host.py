@@ -1,0 +1,177 @@
+"""
+CPU-only checks: the C-ABI library loads and exports every symbol of include/springcraft_hip.h,
+the header and the ctypes table agree, host-side logic (force fields, plans, model objects'
+validation) behaves like the reference's, and the product fails loudly without a GPU.
+"""
+import re
+from os.path import dirname, join
+
+import numpy as np
+import pytest
+
+ROOT = dirname(dirname(__file__))
+
+
+def test_library_exports_every_declared_symbol():
+    from springcraft_amd import _hip
+
+    header = open(join(ROOT, "include", "springcraft_hip.h")).read()
+    declared = set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sc_ctx", "sc_ff_desc", "sc_patch_desc"}
+    assert declared == set(_hip.EXPORTED_SYMBOLS)
+    L = _hip.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import springcraft_amd as sc
+    from springcraft_amd._hip import HipUnavailableError
+
+    with pytest.raises(HipUnavailableError):
+        sc.compute_kirchhoff(np.zeros((4, 3)), sc.InvariantForceField(5.0))
+    with pytest.raises(HipUnavailableError):
+        sc.nma.eigh(np.eye(3))
+
+
+def test_product_does_not_import_oracle():
+    import glob
+
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(.oracle|__import__\(.oracle", re.M)
+    for path in glob.glob(join(ROOT, "springcraft_amd", "**", "*.py"), recursive=True):
+        assert not pat.search(open(path).read()), path
+
+
+def test_public_names():
+    import springcraft_amd as sc
+
+    # reference: springcraft/__init__.py:12-15 and the __all__ lists of its modules
+    for name in ["GNM", "ANM", "ForceField", "PatchedForceField", "InvariantForceField",
+                 "HinsenForceField", "ParameterFreeForceField", "TabulatedForceField",
+                 "compute_kirchhoff", "compute_hessian"]:
+        assert hasattr(sc, name)
+    assert sc.__version__ == "0.3.0"
+
+
+def test_force_constants_match_oracle():
+    import springcraft_amd as sc
+    from oracle import enm_oracle as orc
+
+    rs = np.random.RandomState(0)
+    d2 = rs.rand(1000) * 300 + 1.0
+    i = np.arange(1000)
+    assert np.array_equal(sc.HinsenForceField().force_constant(i, i, d2), orc.hinsen_ff().gamma(i, i, d2))
+    assert np.array_equal(sc.ParameterFreeForceField().force_constant(i, i, d2), 1 / d2)
+    assert np.array_equal(sc.InvariantForceField(7).force_constant(i, i, d2), np.ones(1000))
+
+
+def test_device_plan():
+    import springcraft_amd as sc
+    from springcraft_amd.forcefield import device_plan
+
+    d, patch, fused = device_plan(sc.InvariantForceField(7.0))
+    assert fused and patch is None and d.has_cutoff == 1 and d.cutoff_sq == 49.0
+    d, patch, fused = device_plan(sc.HinsenForceField())
+    assert fused and d.has_cutoff == 0
+    pf = sc.PatchedForceField(sc.HinsenForceField(8.0), contact_shutdown=[1])
+    d, patch, fused = device_plan(pf)
+    assert fused and patch[4] is True
+
+    class Mine(sc.HinsenForceField):
+        def force_constant(self, i, j, d2):
+            return np.full(len(i), 2.0)
+
+    assert device_plan(Mine(9.0))[2] is False       # subclasses may override force_constant
+    nested = sc.PatchedForceField(pf, contact_shutdown=[2])
+    assert device_plan(nested)[2] is False
+    assert list(nested.contact_shutdown) == [2, 1]  # forcefield.py:232-239
+
+
+def test_patched_force_field_host_semantics():
+    """PatchedForceField.force_constant restated (forcefield.py:183-226) vs the reference-generated vectors."""
+    import springcraft_amd as sc
+    from tests.util import generated
+
+    g = generated("patched_n40.npz")
+    ff = sc.PatchedForceField(sc.HinsenForceField(8.0), contact_shutdown=g["shutdown"],
+                              contact_pair_off=g["pair_off"], contact_pair_on=g["pair_on"],
+                              force_constants=g["force_constants"])
+    pairs = g["hinsen8_all_pairs"]
+    coord = g["coord"]
+    disp = coord[pairs[:, 1]] - coord[pairs[:, 0]]
+    d2 = np.sum(disp * disp, axis=-1)
+    gamma = ff.force_constant(pairs[:, 0], pairs[:, 1], d2)
+    k = np.zeros((40, 40))
+    k[pairs[:, 0], pairs[:, 1]] = -gamma
+    np.fill_diagonal(k, -np.sum(k, axis=0))
+    assert np.array_equal(k, g["hinsen8_all_kirchhoff"])
+
+
+def test_tabulated_force_field_shapes():
+    # reference tests: tests/test_forcefield.py:117-334 (construction rules)
+    import springcraft_amd as sc
+
+    atoms = sc.AtomArray(6)
+    atoms.res_name[:] = ["ALA", "GLY", "TRP", "ALA", "TYR", "CYS"]
+    atoms.chain_id[:] = ["A", "A", "A", "B", "B", "B"]
+    atoms.res_id[:] = [1, 2, 3, 1, 2, 4]
+    ff = sc.TabulatedForceField(atoms, 1.0, 2.0, 3.0, 10.0)
+    m = ff.interaction_matrix[:, :, 0]
+    assert m[0, 1] == 1.0 and m[1, 2] == 1.0 and m[3, 4] == 1.0     # bonded
+    assert m[4, 5] == 2.0 and m[0, 2] == 2.0                         # same chain, not adjacent
+    assert m[0, 3] == 3.0 and np.all(np.diag(m) == 0)                # other chain, self
+    assert ff.natoms == 6 and ff.cutoff_distance == 10.0
+    edges = np.array([4.0, 8.0, 12.0])
+    ff = sc.TabulatedForceField(atoms, [1, 2, 3], [4, 5, 6], [7, 8, 9], edges)
+    i = np.array([0, 0, 0]); j = np.array([3, 2, 1])
+    assert list(ff.force_constant(i, j, np.array([3.0, 5.0, 11.0]) ** 2)) == [7, 5, 3]
+    with pytest.raises(ValueError):
+        ff.force_constant(i, j, np.array([3.0, 5.0, 13.0]) ** 2)
+    with pytest.raises(IndexError):
+        sc.TabulatedForceField(atoms, [1, 2], 1, 1, edges)
+    with pytest.raises(ValueError):
+        sc.TabulatedForceField(atoms, 1, np.arange(400.0).reshape(20, 20), 1, 5.0)   # not symmetric
+    with pytest.raises(TypeError):
+        sc.TabulatedForceField(np.zeros((6, 3)), 1, 1, 1, 5.0)
+    bad = atoms.copy()
+    bad.atom_name[0] = "CB"
+    with pytest.raises(sc.atoms.BadStructureError):
+        sc.TabulatedForceField(bad, 1, 1, 1, 5.0)
+
+
+def test_model_validation_without_gpu():
+    import springcraft_amd as sc
+
+    coord = np.random.RandomState(0).rand(10, 3)
+    ff = sc.InvariantForceField(5.0)
+    with pytest.raises(TypeError):
+        sc.ANM(coord, ff, masses=True)
+    atoms = sc.AtomArray(10)
+    atoms.coord = coord
+    with pytest.raises(IndexError):
+        sc.ANM(atoms, ff, masses=np.ones(9))
+    with pytest.raises(ValueError):
+        sc.GNM(atoms, ff, masses=np.zeros(10))
+    anm = sc.ANM(atoms, ff, masses=np.full(10, 4.0))
+    assert np.allclose(anm._inv_sqrt_mass, 0.5) and anm.masses.shape == (10,)
+    h = np.eye(30)
+    anm.hessian = h
+    assert anm.hessian is h                                   # not a copy (anm.py:53)
+    assert np.allclose(anm.covariance, np.eye(30))
+    anm.covariance = 2 * np.eye(30)
+    assert np.allclose(anm.hessian, 0.5 * np.eye(30))          # rebuilt by pinv (anm.py:114-117)
+
+
+def test_shard_bounds():
+    from springcraft_amd.batch import shard_bounds
+
+    for n_items, world in [(256, 8), (10, 3), (3, 8), (0, 4)]:
+        spans = [shard_bounds(n_items, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n_items
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

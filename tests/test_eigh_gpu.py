@@ -1,0 +1,203 @@
+"""
+GPU parity tests for the eigensolve half of the hot path (the HIP replacement of
+``np.linalg.eigh`` at the reference's nma.py:61), called through the Python API -> C ABI.
+
+Gates: eigenvalues within 1e-5 relative of the reference's for the
+non-trivial modes and |lambda| <= 1e-9 lambda_max for the trivial ones; eigenvectors by residual
+||A v - lambda v|| <= 1e-5 ||A||, orthogonality ||V V^T - I||_max <= 1e-8, and |<v, v_ref>| >= 1 - 1e-5
+for well separated modes.  The solver actually reaches ~1e-14, which the tests also pin (1e-11).
+"""
+import numpy as np
+import pytest
+
+from oracle import enm_oracle as orc
+from tests.util import (check_eigenvalues, check_eigenvectors, generated, load_csv, structures,
+                        synthetic_coord)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    import springcraft_amd
+
+    return springcraft_amd
+
+
+def sym(rs, n):
+    a = rs.randn(n, n)
+    return a + a.T
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 130, 200, 513, 1000])
+def test_random_symmetric(sc, n):
+    """Every size class: single leaf, odd splits, n = 0/1/2 mod the panel width, several D&C levels."""
+    a = sym(np.random.RandomState(n), n)
+    w, v = sc.nma.eigh(a)
+    w_ref = np.linalg.eigvalsh(a)
+    assert np.abs(w - w_ref).max() <= 1e-11 * max(np.abs(w_ref).max(), 1e-300)
+    check_eigenvectors(a, w, v, tol_res=1e-11, tol_orth=1e-11)
+    w_only = sc.nma.eigh(a, eigenvectors=False)
+    assert np.abs(w_only - w_ref).max() <= 1e-11 * max(np.abs(w_ref).max(), 1e-300)
+
+
+def test_only_lower_triangle_is_read(sc):
+    """np.linalg.eigh(UPLO='L') semantics: garbage in the strict upper triangle must not matter."""
+    rs = np.random.RandomState(5)
+    a = sym(rs, 150)
+    junk = a.copy()
+    junk[np.triu_indices(150, 1)] = rs.randn(150 * 149 // 2) * 100
+    w, v = sc.nma.eigh(junk)
+    w_ref, _ = np.linalg.eigh(junk)  # also reads the lower triangle only
+    assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    check_eigenvectors(a, w, v, tol_res=1e-11, tol_orth=1e-11)
+    assert np.array_equal(junk[np.triu_indices(150, 1)], junk[np.triu_indices(150, 1)])  # input untouched
+
+
+@pytest.mark.parametrize("kind", ["identity", "diag", "tridiagonal", "degenerate4", "rank1", "wilkinson",
+                                  "zero", "graded"])
+def test_structured(sc, kind):
+    """Deflation-heavy spectra: exercise both deflation types, exact zeros and clustered poles."""
+    n = 300
+    rs = np.random.RandomState(11)
+    q, _ = np.linalg.qr(rs.randn(n, n))
+    if kind == "identity":
+        a = np.eye(n)
+    elif kind == "zero":
+        a = np.zeros((n, n))
+    elif kind == "diag":
+        a = np.diag(rs.randn(n))
+    elif kind == "tridiagonal":
+        a = np.diag(rs.randn(n)) + np.diag(rs.randn(n - 1), 1)
+        a = np.triu(a) + np.triu(a, 1).T
+    elif kind == "degenerate4":
+        a = (q * np.repeat(rs.randn(n // 4), 4)) @ q.T
+    elif kind == "rank1":
+        a = np.eye(n) + 5 * np.outer(q[:, 0], q[:, 0])
+    elif kind == "wilkinson":
+        a = np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    elif kind == "graded":
+        a = (q * np.logspace(-12, 3, n)) @ q.T
+    a = 0.5 * (a + a.T)
+    w, v = sc.nma.eigh(a)
+    w_ref = np.linalg.eigvalsh(a)
+    scale = max(np.abs(w_ref).max(), 1e-300)
+    assert np.abs(w - w_ref).max() <= 1e-11 * scale
+    r = np.abs(a @ v.T - v.T * w[None, :]).max()
+    assert r <= 1e-11 * max(scale, 1.0)
+    assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-11
+
+
+# ---- the reference's eigen goldens ------------------------------------------------------------------
+
+@pytest.mark.parametrize("cutoff", [4, 7])
+def test_gnm_eigen_prody_1l2y(sc, cutoff):
+    # reference test: tests/test_gnm.py:47-84 (values and vectors, sign fixed by the first component)
+    ca = structures()["1l2y_coord"]
+    w, v = sc.GNM(ca, sc.InvariantForceField(cutoff)).eigen()
+    ref_w = load_csv(f"prody_gnm_{cutoff}_ang_cutoff_evals_1l2y.csv.gz")
+    ref_v = load_csv(f"prody_gnm_{cutoff}_ang_cutoff_evecs_1l2y.csv.gz")
+    v = v * np.sign(v[:, 0])[:, None]
+    ref_v = ref_v * np.sign(ref_v[:, 0])[:, None]
+    assert np.allclose(w[1:], ref_w[1:])
+    assert w[1:].tolist() == pytest.approx(ref_w[1:].tolist())
+    assert v[1:].ravel().tolist() == pytest.approx(ref_v[1:].ravel().tolist(), abs=1e-6)
+
+
+@pytest.mark.parametrize("name", ["1l2y", "7cal"])
+def test_anm_eigenvalues_prody(sc, name):
+    """ProDy ANM 13 A eigenvalues; 7cal is the n = 5328 case (fixture of tests/test_anm.py:145-334)."""
+    ca = structures()[f"{name}_coord"]
+    w, v = sc.ANM(ca, sc.InvariantForceField(13.0)).eigen()
+    ref = load_csv(f"prody_anm_13_ang_cutoff_evals_{name}.csv.gz")
+    check_eigenvalues(w, np.concatenate([np.zeros(6), ref[6:]]), 6, rtol=1e-5)
+    assert v.shape == (len(w), len(w))
+
+
+@pytest.mark.parametrize("ff_name", ["calpha", "pfanm"])
+@pytest.mark.parametrize("name", ["1l2y", "7cal"])
+def test_mass_weighted_eigenvalues_bio3d(sc, name, ff_name):
+    # reference test: tests/test_anm.py:87-142 (Hinsen and pfENM legs; rtol 5e-3, atol 2e-3)
+    s = structures()
+    n = len(s[f"{name}_coord"])
+    atoms = sc.AtomArray(n)
+    atoms.coord = s[f"{name}_coord"]
+    atoms.res_name = s[f"{name}_res_name"]
+    ff = sc.HinsenForceField() if ff_name == "calpha" else sc.ParameterFreeForceField()
+    masses = load_csv(f"bio3d_mass_{name}.csv.gz")
+    w, _ = sc.ANM(atoms, ff, masses=masses).eigen()
+    ref = load_csv(f"bio3d_anm_{ff_name}_ff_evals_mw_{name}.csv.gz")
+    assert np.allclose(w[6:], ref[6:], rtol=5e-3, atol=2e-3)
+
+
+# ---- benchmark configurations against the reference-generated eigenvalues --------------------------------
+
+def test_config1_gnm(sc):
+    g = generated("c1_1l2y_gnm7.npz")
+    w, v = sc.GNM(structures()["1l2y_coord"], sc.InvariantForceField(7.0)).eigen()
+    check_eigenvalues(w, g["eigenvalues"], 1)
+    check_eigenvectors(g["kirchhoff"], w, v)
+
+
+def test_config2_anm_n512(sc):
+    g = generated("c2_n512_inv13.npz")
+    coord = synthetic_coord(512, 0, 40.0)
+    anm = sc.ANM(coord, sc.InvariantForceField(13.0))
+    w, v = anm.eigen()                       # fused: coordinates -> eigenpairs on device
+    check_eigenvalues(w, g["eigenvalues"], 6)
+    h, _ = orc.compute_hessian(coord, orc.invariant_ff(13.0))
+    check_eigenvectors(h, w, v)
+    lo, hi = g["eigenvectors_sel_range"]
+    overlap = np.abs(np.sum(v[lo:hi] * g["eigenvectors_sel"], axis=1))
+    gaps = np.minimum(np.diff(w)[lo - 1:hi - 1], np.diff(w)[lo:hi]) / w[lo:hi]
+    assert np.all(overlap[gaps > 1e-3] >= 1 - 1e-5)
+    # second route: host matrix (user-assignable, anm.py:120-130) through sc_eigh_f64
+    w2, v2 = sc.nma.eigh(anm.hessian)
+    assert np.abs(w2 - w).max() <= 1e-10 * w.max()
+
+
+def test_config3_anm_n2000_hinsen(sc):
+    """The headline configuration: N=2000 C-alpha, Hinsen, no cutoff, all 6000 modes."""
+    g = generated("c3_n2000_hinsen.npz")
+    coord = synthetic_coord(2000, 0)
+    w, v = sc.ANM(coord, sc.HinsenForceField()).eigen()
+    check_eigenvalues(w, g["nocut_eigenvalues"], 6)
+    # size-independent properties at full size: orthonormality and residual on sampled modes
+    rs = np.random.RandomState(0)
+    sel = np.sort(rs.choice(6000, 64, replace=False))
+    gram = v[sel] @ v.T
+    assert np.abs(gram - np.eye(6000)[sel]).max() <= 1e-8
+    h, _ = orc.compute_hessian(coord, orc.hinsen_ff())
+    r = h @ v[sel].T - v[sel].T * w[sel][None, :]
+    assert np.linalg.norm(r, axis=0).max() <= 1e-5 * w.max()
+    assert abs(w.sum() - np.trace(h)) <= 1e-9 * np.abs(w).sum()       # trace is preserved
+    lo, hi = g["nocut_eigenvectors_sel_range"]
+    overlap = np.abs(np.sum(v[lo:hi] * g["nocut_eigenvectors_sel"], axis=1))
+    gaps = np.minimum(np.diff(w)[lo - 1:hi - 1], np.diff(w)[lo:hi]) / w[lo:hi]
+    assert np.all(overlap[gaps > 1e-3] >= 1 - 1e-5)
+
+
+def test_config4_anm_n1000_batch_members(sc):
+    g = generated("c4_n1000_inv13.npz")
+    for seed in range(2):
+        w, _ = sc.ANM(synthetic_coord(1000, seed, 50.0), sc.InvariantForceField(13.0)).eigen()
+        check_eigenvalues(w, g[f"s{seed}_eigenvalues"], 6)
+
+
+def test_consumers_run_on_device_eigen(sc):
+    """The NumPy consumers (nma.py:66-569) keep working on top of the device eigensolver."""
+    ca = structures()["1l2y_coord"]
+    anm = sc.ANM(ca, sc.InvariantForceField(13.0))
+    h_ref, _ = orc.compute_hessian(ca, orc.invariant_ff(13.0))
+    w_ref, v_ref = np.linalg.eigh(h_ref)
+    f = anm.frequencies()
+    assert np.allclose(f[6:], np.sqrt(w_ref[6:]) / (2 * np.pi))
+    msf = anm.mean_square_fluctuation()
+    cov = np.linalg.pinv(h_ref, hermitian=True, rcond=1e-6)
+    assert np.allclose(msf, np.diag(cov).reshape(-1, 3).sum(1))
+    d = anm.dcc()
+    assert d.shape == (20, 20) and np.allclose(np.diag(d), 1.0)
+    assert anm.normal_mode(6, 2.0, 10).shape == (10, 20, 3)
+    assert np.allclose(anm.hessian @ anm.covariance @ anm.hessian, anm.hessian)  # tests/test_anm.py:26-37
+    with pytest.raises(ValueError):
+        sc.nma.eigen(object())                                                # nma.py:58
