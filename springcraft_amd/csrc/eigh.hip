@@ -24,11 +24,12 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
   L.xraw = take(n);
   L.ypart = take(nt * n);
   L.dpart = take(nt * 2 * kNb);
-  L.npart = take(n / 256 + 8);
-  L.wvpart = take(n / 256 + 8);
+  L.npart = take(nt + 8);
+  L.wvpart = take(nt + 8);
   L.d = take(n);
   L.e = take(n);
   L.tau = take(n);
+  L.hscale = take(8);
   L.slab = off;
   if (out) *out = L;
   return (size_t)off;

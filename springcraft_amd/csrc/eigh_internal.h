@@ -17,6 +17,7 @@ struct TriLayout {
   long long npart;   // partial squared norms (<= n/256 + 1)
   long long wvpart;  // partial w~^T v
   long long d, e, tau;  // tridiagonal + reflector scalars (n each)
+  long long hscale;     // [0] = 1/(alpha - beta) of the current column (written by k_symv_tiles)
 };
 
 // d_a: (batch) n x n column-major, lower triangle valid after the mirror pass; on exit column c holds

@@ -12,6 +12,9 @@
 // The MFMA is fed "swapped" (its A operand comes from the B tile, its B operand from the A tile):
 // the accumulator then holds C^T fragments whose 16 consecutive lanes map to 16 consecutive ROWS
 // of the column-major C, so C loads / stores are 128-byte contiguous segments.
+#include <cmath>
+#include <vector>
+
 #include "gemm_f64.h"
 
 namespace {
@@ -137,14 +140,44 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const GemmDesc* __restrict_
   };
 
   d4 acc[NT][MT];
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = d4{0.0, 0.0, 0.0, 0.0};
-
   const int fr = lane & 15, fk = lane >> 4;
 
+  // C(row = m0 + wm*WM + mi*16 + fr, col = n0 + wn*WN + ni*16 + fk + 4r) <-> acc[ni][mi][r]
+  double* __restrict__ C = D.c + (split_k > 1 ? (long long)slice * D.split_stride : 0LL);
+  const double alpha = D.alpha;
+  const double beta = split_k > 1 ? 0.0 : D.beta;
+  const long long ldc = D.ldc;
+  const int* __restrict__ jidx = D.c_jidx;
+  const bool lower = D.lower_only != 0;
+  const int roff = D.row_off, coff = D.col_off;
+
   load_tiles(k_begin);
+  // beta * C goes straight into the accumulators (scaled by 1/alpha), its loads in flight together with
+  // the first operand tiles: the epilogue is then store-only.
+  if (beta != 0.0 && alpha != 0.0) {
+    const double scale = beta / alpha;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
+        const long long dcol = (jidx && col < N) ? (long long)jidx[col] : (long long)col;
+        const double* ccol = C + dcol * ldc;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int row = m0 + wm * WM + mi * 16 + fr;
+          double v = 0.0;
+          if (col < N && row < M && !(lower && (row + roff) < (col + coff))) v = ccol[row] * scale;
+          acc[ni][mi][r] = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = d4{0.0, 0.0, 0.0, 0.0};
+  }
   store_tiles(0);
   __syncthreads();
   int buf = 0;
@@ -171,14 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const GemmDesc* __restrict_
     buf ^= 1;
   }
 
-  // ---- epilogue: acc[ni][mi][r] = C(row = m0 + wm*WM + mi*16 + fr, col = n0 + wn*WN + ni*16 + fk + 4r)
-  double* __restrict__ C = D.c + (split_k > 1 ? (long long)slice * D.split_stride : 0LL);
-  const double alpha = D.alpha;
-  const double beta = split_k > 1 ? 0.0 : D.beta;
-  const long long ldc = D.ldc;
-  const int* __restrict__ jidx = D.c_jidx;
-  const bool lower = D.lower_only != 0;
-  const int roff = D.row_off, coff = D.col_off;
+  // ---- epilogue (store only)
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
 #pragma unroll
@@ -192,9 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const GemmDesc* __restrict_
         const int row = m0 + wm * WM + mi * 16 + fr;
         if (row >= M) continue;
         if (lower && (row + roff) < (col + coff)) continue;
-        double v = alpha * acc[ni][mi][r];
-        if (beta != 0.0) v += beta * ccol[row];
-        ccol[row] = v;
+        ccol[row] = alpha * acc[ni][mi][r];
       }
     }
   }
@@ -215,5 +239,70 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   else
     hipLaunchKernelGGL(k_gemm_f64<128>, grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// ---- debug / tuning entry point (not part of the public C ABI) ----------------------------------------------
+// Times `iters` launches of one GEMM shape on freshly allocated buffers.  mode: 0 = NN (A m x k col-major,
+// B k x n col-major), 1 = NT lower-only (SYR2K shape: B stored n x k), 2 = TN (A stored k x m).
+extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int split_k, int iters,
+                                 int beta_one, double* ms_out, double* max_err_out) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t ea = (size_t)m * k, eb = (size_t)k * n, ec = (size_t)m * n * (split_k > 1 ? split_k : 1);
+  double *a, *b, *c;
+  GemmDesc* dd;
+  SC_HIP(ctx, hipMalloc(&a, ea * 8));
+  SC_HIP(ctx, hipMalloc(&b, eb * 8));
+  SC_HIP(ctx, hipMalloc(&c, ec * 8));
+  SC_HIP(ctx, hipMalloc(&dd, sizeof(GemmDesc)));
+  std::vector<double> ha(ea), hb(eb), hc(ec, 0.0);
+  unsigned long long s = 88172645463325252ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)((long long)(s % 2001) - 1000) / 1000.0; };
+  for (auto& x : ha) x = rnd();
+  for (auto& x : hb) x = rnd();
+  SC_HIP(ctx, hipMemcpy(a, ha.data(), ea * 8, hipMemcpyHostToDevice));
+  SC_HIP(ctx, hipMemcpy(b, hb.data(), eb * 8, hipMemcpyHostToDevice));
+  SC_HIP(ctx, hipMemset(c, 0, ec * 8));
+  GemmDesc D{};
+  D.a = a; D.b = b; D.c = c; D.m = m; D.n = n; D.k = k; D.ldc = m;
+  D.alpha = 1.0; D.beta = beta_one ? 1.0 : 0.0;
+  if (mode == 0) { D.sa_i = 1; D.sa_k = m; D.sb_k = 1; D.sb_j = k; }
+  if (mode == 1) { D.sa_i = 1; D.sa_k = m; D.sb_k = n; D.sb_j = 1; D.lower_only = 1; }
+  if (mode == 2) { D.sa_i = k; D.sa_k = 1; D.sb_k = 1; D.sb_j = k; }
+  D.split_stride = (long long)m * n;
+  SC_HIP(ctx, hipMemcpy(dd, &D, sizeof(D), hipMemcpyHostToDevice));
+  SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k));
+  SC_HIP(ctx, hipStreamSynchronize(st));
+  // spot check 64 entries against a host dot product (beta path: C was 0 before the first launch)
+  SC_HIP(ctx, hipMemcpy(hc.data(), c, ec * 8, hipMemcpyDeviceToHost));
+  double maxerr = 0.0;
+  for (int t = 0; t < 64; ++t) {
+    int i = (int)((t * 7919ull) % m), j = (int)((t * 104729ull) % n);
+    if (mode == 1 && i < j) { int tmp = i; i = j; j = tmp; if (i >= m || j >= n) continue; }
+    double ref = 0.0;
+    for (int kk = 0; kk < k; ++kk) {
+      const double av = mode == 2 ? ha[(size_t)i * k + kk] : ha[(size_t)kk * m + i];
+      const double bv = mode == 1 ? hb[(size_t)kk * n + j] : hb[(size_t)j * k + kk];
+      ref += av * bv;
+    }
+    double got = 0.0;
+    for (int sl = 0; sl < (split_k > 1 ? split_k : 1); ++sl) got += hc[(size_t)sl * m * n + (size_t)j * m + i];
+    maxerr = fmax(maxerr, fabs(got - ref));
+  }
+  if (max_err_out) *max_err_out = maxerr;
+  hipEvent_t e0, e1;
+  SC_HIP(ctx, hipEventCreate(&e0));
+  SC_HIP(ctx, hipEventCreate(&e1));
+  SC_HIP(ctx, hipEventRecord(e0, st));
+  for (int it = 0; it < iters; ++it) SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k));
+  SC_HIP(ctx, hipEventRecord(e1, st));
+  SC_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  SC_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  if (ms_out) *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(dd);
   return SC_OK;
 }

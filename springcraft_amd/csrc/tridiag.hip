@@ -12,6 +12,8 @@
 // next k_col_update (w = w~ + alpha2 v), so a column costs three launches.
 //
 // All kernels take blockIdx.y = matrix index of the batch.
+#include <algorithm>
+
 #include "eigh_internal.h"
 
 namespace {
@@ -49,33 +51,52 @@ __device__ __forceinline__ HH householder(double alpha, double xn2) {
   return h;
 }
 
-__device__ __forceinline__ double sum_partials(const double* p, int cnt) {
+// Sum of `cnt` partial results written by the previous kernel: coalesced loads, fixed reduction tree
+// (deterministic), result in every thread.  Needs all 256 threads of the block; contains barriers.
+__device__ __forceinline__ double sum_partials(const double* p, int cnt, double* sh /*[blockDim/64]*/) {
+  double v = 0.0;
+  for (int q = threadIdx.x; q < cnt; q += (int)blockDim.x) v += p[q];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
   double s = 0.0;
-  for (int q = 0; q < cnt; ++q) s += p[q];
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  __syncthreads();
   return s;
 }
 
+// Rows are tiled in ABSOLUTE blocks of 64 (block B = rows 64B .. 64B+63), not relative to the
+// current column: every 64-row segment then starts on an even row, so with an even matrix order the
+// SYMV tiles can be fetched with 16-byte loads, and the partial-result tables keep the same indexing
+// from one column to the next.  For column c the active rows are c+1 .. n-1, i.e. blocks
+// b0 = (c+1)/64 .. nba-1 with nba = ceil(n/64); rows of block b0 below c+1 are masked.
+
+__device__ __forceinline__ int first_block(int row) { return row >> 6; }
+
 // ---- column update -------------------------------------------------------------------------------------
-// rows r = c .. n-1, one thread per row.  i = c - j0 reflectors of the current panel are pending.
-__global__ __launch_bounds__(256) void k_col_update(double* __restrict__ a_all, long long stride_a,
-                                                    double* __restrict__ ws_all, TriLayout L, int c,
-                                                    int j0) {
-  __shared__ double rowV[64], rowW[64], red[5];
+// a = A[:,c] - V W[c,:]^T - W V[c,:]^T for rows c .. n-1 (i = c - j0 pending reflectors).
+// Block = 64 absolute rows x 4 groups that split the reflector range; group sums meet in LDS.
+__global__ __launch_bounds__(1024) void k_col_update(double* __restrict__ a_all, long long stride_a,
+                                                     double* __restrict__ ws_all, TriLayout L, int c,
+                                                     int j0) {
+  constexpr int NG = 16;
+  __shared__ double rowV[64], rowW[64], part[NG][64], sh[16], arow[64];
   const int n = L.n, nb = L.nb, i = c - j0;
+  const int nba = (n + 63) >> 6;
   double* A = a_all + (size_t)blockIdx.y * stride_a;
   double* ws = ws_all + (size_t)blockIdx.y * L.slab;
   double* VW = ws + L.vw;
   double* WV = ws + L.wv;
-  const int tid = threadIdx.x;
-  const int r = c + blockIdx.x * 256 + tid;
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int r = ((c >> 6) + blockIdx.x) * 64 + lane;
+  const bool valid = r >= c && r < n;
 
   double alpha2 = 0.0;
-  if (i > 0) {
+  if (i > 0) {  // block-uniform
     const double tau_prev = ws[L.tau + c - 1];
-    if (tau_prev != 0.0) {
-      const int cnt = (n - c + 255) / 256;  // blocks of k_w_reduce(c-1): m_prev = n - c rows
-      alpha2 = -0.5 * tau_prev * sum_partials(ws + L.wvpart, cnt);
-    }
+    const int cnt = nba - first_block(c);  // blocks of k_w_reduce(c-1): rows c .. n-1
+    const double s = sum_partials(ws + L.wvpart, cnt, sh);
+    if (tau_prev != 0.0) alpha2 = -0.5 * tau_prev * s;
   }
   if (tid < i) {
     const int p = tid;
@@ -87,10 +108,15 @@ __global__ __launch_bounds__(256) void k_col_update(double* __restrict__ a_all, 
   }
   __syncthreads();
 
-  double sq = 0.0;
-  if (r < n) {
-    double a = A[(size_t)c * n + r];
-    for (int p = 0; p < i; ++p) {
+  // each group owns reflectors p = g, g+16, g+32, g+48 (nb <= 64): keep their V / W entries for the dots below
+  double vk[4], wk[4];
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = g + NG * u;
+    vk[u] = 0.0;
+    wk[u] = 0.0;
+    if (valid && p < i) {
       const double v = VW[(size_t)p * n + r];
       double w = VW[(size_t)(nb + p) * n + r];
       if (p == i - 1 && alpha2 != 0.0) {
@@ -102,195 +128,290 @@ __global__ __launch_bounds__(256) void k_col_update(double* __restrict__ a_all, 
           WV[(size_t)p * n + r] = w;          // W column of [W|V]
         }
       }
-      a -= v * rowW[p] + w * rowV[p];
+      acc += v * rowW[p] + w * rowV[p];
+      vk[u] = v;
+      wk[u] = w;
     }
-    ws[L.xraw + r] = a;
-    if (r == c) ws[L.d + c] = a;
-    if (r == c + 1 && c == n - 2) {  // last sub-diagonal element: no reflector (dsytd2: tau = 0)
-      ws[L.e + c] = a;
-      ws[L.tau + c] = 0.0;
-    }
-    if (r >= c + 2) sq = a * a;
   }
-  const double s = block_sum_bcast(sq, red);
-  if (tid == 0) ws[L.npart + blockIdx.x] = s;
+  part[g][lane] = acc;
+  __syncthreads();
+  if (g == 0) {
+    double sq = 0.0, a = 0.0;
+    if (valid) {
+      double corr = 0.0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) corr += part[q][lane];
+      a = A[(size_t)c * n + r] - corr;
+      ws[L.xraw + r] = a;
+      if (r == c) ws[L.d + c] = a;
+      if (r == c + 1 && c == n - 2) {  // last sub-diagonal element: no reflector (dsytd2: tau = 0)
+        ws[L.e + c] = a;
+        ws[L.tau + c] = 0.0;
+      }
+      if (r >= c + 2) sq = a * a;
+    }
+    arow[lane] = (valid && r >= c + 2) ? a : 0.0;   // rows below the reflector's unit entry
+    sq = wave_sum(sq);
+    if (lane == 0) ws[L.npart + blockIdx.x] = sq;
+  }
+  __syncthreads();
+  // Partial dots for the panel corrections of THIS column's reflector v = (1, scale * a[c+2:]):
+  //   V_p^T v = scale * sum_{r >= c+2} V[r,p] a[r] + V[c+1,p]   (same for W); the sums are taken here, where the
+  // V / W entries are already in registers; k_w_reduce adds the scale and the unit-entry term.
+  const double ar = arow[lane];
+  const int blk = (c >> 6) + blockIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = g + NG * u;
+    if (p < i) {  // wave-uniform
+      const double sv = wave_sum(vk[u] * ar);
+      const double sw = wave_sum(wk[u] * ar);
+      if (lane == 0) {
+        ws[L.dpart + (size_t)blk * 2 * nb + p] = sv;
+        ws[L.dpart + (size_t)blk * 2 * nb + nb + p] = sw;
+      }
+    }
+  }
 }
 
 // ---- symmetric matrix-vector product on lower 64x64 tiles ---------------------------------------------------
-// grid.x = nt (nt+1)/2 tiles (bi >= bj) of the trailing matrix A22 = A[c+1:, c+1:], m = n-c-1.
-__global__ __launch_bounds__(256) void k_symv_tiles(double* __restrict__ a_all, long long stride_a,
-                                                    double* __restrict__ ws_all, TriLayout L, int c,
-                                                    int j0) {
-  constexpr int TS = 64, LD = 65;
-  __shared__ double T[TS * LD];
-  __shared__ double xi[TS], xj[TS];
-  __shared__ double red[4][TS];
-  const int n = L.n, nb = L.nb, i = c - j0;
-  const int m = n - c - 1;
-  double* A = a_all + (size_t)blockIdx.y * stride_a;
-  double* ws = ws_all + (size_t)blockIdx.y * L.slab;
-  const int tid = threadIdx.x;
+// Tiles (bi >= bj) over the absolute row blocks b0 .. nba-1 of the trailing matrix; ntiles = nt (nt+1)/2.
+// Persistent blocks: block g walks tiles g, g+G, g+2G, ...; as soon as the current tile has been parked in LDS
+// the NEXT tile's 16 doubles per thread (and its x segments) are requested into the same registers and stay in
+// flight while the current tile is multiplied, so every resident block always has 32 KB of HBM reads outstanding.  Barriers are raw s_barrier + lgkmcnt(0): they only order
+// LDS traffic and must not drain the prefetch (a __syncthreads() would wait for vmcnt(0)).
+// Each tile is fetched once and used for both  y_i += T x_j  and  y_j += T^T x_i.
+// VEC2: 16-byte loads (needs an even matrix order).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-  // Householder scalars (every block recomputes them from the same partials, in the same order)
-  const double xn2 = sum_partials(ws + L.npart, (n - c + 255) / 256);
-  const double alpha = ws[L.xraw + c + 1];
-  const HH h = householder(alpha, xn2);
-
-  // tile coordinates
-  const int t = blockIdx.x;
-  int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while (bi * (bi + 1) / 2 > t) --bi;
-  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-  const int bj = t - bi * (bi + 1) / 2;
-  const bool diag = (bi == bj);
-  const int r0 = bi * TS, k0 = bj * TS;
-
-  if (tid < TS) {
-    const int rr = r0 + tid;
-    xi[tid] = rr < m ? (rr == 0 ? 1.0 : ws[L.xraw + c + 1 + rr] * h.scale) : 0.0;
-  } else if (tid < 2 * TS) {
-    const int kk = k0 + tid - TS;
-    xj[tid - TS] = kk < m ? (kk == 0 ? 1.0 : ws[L.xraw + c + 1 + kk] * h.scale) : 0.0;
-  }
-  // load tile: element (rr, kk) = A22[r0+rr, k0+kk] = A[(c+1+r0+rr) + (c+1+k0+kk) n]
-  {
-    const int rr = tid & 63;
-    const int kq = tid >> 6;
-    const int gr = r0 + rr;
-    const double* base = A + (size_t)(c + 1 + k0) * n + (c + 1 + gr);
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-      const int kk = kq + 4 * q;
-      const int gk = k0 + kk;
-      double v = 0.0;
-      if (gr < m && gk < m) v = base[(size_t)kk * n];
-      T[rr + kk * LD] = v;
-    }
-  }
-  __syncthreads();
-
-  const int lane = tid & 63, q = tid >> 6;
-  if (diag) {
-    // y[r] = sum_k Tsym[r,k] x[k], Tsym from the lower triangle only
-    double acc = 0.0;
-#pragma unroll 4
-    for (int kk = q * 16; kk < q * 16 + 16; ++kk) {
-      const double tv = (lane >= kk) ? T[lane + kk * LD] : T[kk + lane * LD];
-      acc += tv * xj[kk];
-    }
-    red[q][lane] = acc;
-    __syncthreads();
-    if (tid < TS && r0 + tid < m)
-      ws[L.ypart + (size_t)bj * n + r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-  } else {
-    double acc = 0.0;
-#pragma unroll 4
-    for (int kk = q * 16; kk < q * 16 + 16; ++kk) acc += T[lane + kk * LD] * xj[kk];
-    red[q][lane] = acc;
-    __syncthreads();
-    if (tid < TS && r0 + tid < m)
-      ws[L.ypart + (size_t)bj * n + r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    __syncthreads();
-    // transposed product: y_j[k] += sum_r T[r,k] x_i[r]
-    acc = 0.0;
-#pragma unroll 4
-    for (int rr = q * 16; rr < q * 16 + 16; ++rr) acc += T[rr + lane * LD] * xi[rr];
-    red[q][lane] = acc;
-    __syncthreads();
-    if (tid < TS && k0 + tid < m)
-      ws[L.ypart + (size_t)bi * n + k0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-  }
-
-  if (diag) {
-    // store v (explicit leading 1) for the back-transformation and into both panel copies
-    double* VW = ws + L.vw;
-    double* WV = ws + L.wv;
-    if (tid < TS && r0 + tid < m) {
-      const double xv = xi[tid];
-      const size_t row = (size_t)c + 1 + r0 + tid;
-      A[(size_t)c * n + row] = xv;
-      VW[(size_t)i * n + row] = xv;
-      WV[(size_t)(nb + i) * n + row] = xv;
-    }
-    // partial dots for the panel corrections: dpart[bi][p] = sum_rows V[r,p] x[r]  (p < i),
-    //                                         dpart[bi][nb+p] = sum_rows W[r,p] x[r]
-    const int row = c + 1 + r0 + lane;
-    const bool rv = (r0 + lane) < m;
-    const double xv = rv ? xi[lane] : 0.0;
-    for (int p = q; p < 2 * i; p += 4) {
-      const int col = p < i ? p : nb + (p - i);
-      double v = rv ? VW[(size_t)col * n + row] * xv : 0.0;
-      v = wave_sum(v);
-      if (lane == 0) ws[L.dpart + (size_t)bi * 2 * nb + col] = v;
-    }
-    if (t == 0 && tid == 0) {
-      ws[L.e + c] = h.beta;
-      ws[L.tau + c] = h.tau;
-    }
-  }
+__device__ __forceinline__ void tile_coords(int t, int& ti, int& tj) {
+  ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  tj = t - ti * (ti + 1) / 2;
 }
 
-// ---- reduce partial products, apply panel corrections, scale by tau ---------------------------------------
-// one thread per row r' = 0..m-1 of v / w
-__global__ __launch_bounds__(256) void k_w_reduce(double* __restrict__ a_all, long long stride_a,
-                                                  double* __restrict__ ws_all, TriLayout L, int c,
-                                                  int j0) {
-  __shared__ double dots[128], red[5];
+template <bool VEC2>
+__global__ __launch_bounds__(256, 4) void k_symv_tiles(double* __restrict__ a_all, long long stride_a,
+                                                    double* __restrict__ ws_all, TriLayout L, int c,
+                                                    int j0, int ntiles) {
+  constexpr int TS = 64, LD = 66;
+  __shared__ __attribute__((aligned(16))) double T[TS * LD];
+  __shared__ double xi[TS], xj[TS];
+  __shared__ double red[4][TS];
+  __shared__ double sh[4];
   const int n = L.n, nb = L.nb, i = c - j0;
-  const int m = n - c - 1;
-  const int nt = (m + 63) / 64;
-  const double* A = a_all + (size_t)blockIdx.y * stride_a;
+  const int nba = (n + 63) >> 6, b0 = first_block(c + 1);
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
   double* ws = ws_all + (size_t)blockIdx.y * L.slab;
   double* VW = ws + L.vw;
   double* WV = ws + L.wv;
   const int tid = threadIdx.x;
+  const int first = c + 1;
+  const int lr = tid & 31, kq = tid >> 5;
+  const int lane = tid & 63, q = tid >> 6;
 
-  if (tid < 2 * nb) {
-    const int p = tid < nb ? tid : tid - nb;
+  // loads of one tile: thread (lr, kq) owns rows r0+2lr, r0+2lr+1 of columns k0 + kq + 8p; threads < 128 also
+  // fetch one raw x entry each (xi for tid < 64, xj for 64 <= tid < 128)
+  // All loads are UNCONDITIONAL (addresses clamped into the matrix): a predicated load merged with a zero
+  // makes hipcc wait for each load right after issuing it.  Masking happens when the tile goes to LDS.
+  auto issue = [&](int t, double (&v0)[8], double (&v1)[8], double& xr) {
+    int ti, tj;
+    tile_coords(t, ti, tj);
+    const int r0 = (b0 + ti) * TS, k0 = (b0 + tj) * TS;
+    const int row = min(r0 + 2 * lr, VEC2 ? n - 2 : n - 1);
+    const double* base = A + row;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int col = min(k0 + kq + 8 * p, n - 1);
+      const double* ptr = base + (size_t)col * n;
+      if (VEC2) {
+        const double2 d2 = *reinterpret_cast<const double2*>(ptr);
+        v0[p] = d2.x;
+        v1[p] = d2.y;
+      } else {
+        v0[p] = ptr[0];
+        v1[p] = ptr[row + 1 < n ? 1 : 0];
+      }
+    }
+    const int rr = min(((tid & 64) ? k0 : r0) + (tid & 63), n - 1);
+    xr = ws[L.xraw + rr];
+  };
+
+  double c0[8], c1[8], cx;
+  int t = blockIdx.x;
+  issue(t, c0, c1, cx);
+
+  // Householder scalars (every block recomputes them from the same partials, in the same order)
+  const double xn2 = sum_partials(ws + L.npart, nba - first_block(c), sh);
+  const double alpha = ws[L.xraw + c + 1];
+  const HH h = householder(alpha, xn2);
+
+  while (t < ntiles) {
+    int ti, tj;
+    tile_coords(t, ti, tj);
+    const int bi = b0 + ti, bj = b0 + tj;
+    const bool diag = (bi == bj);
+    const int r0 = bi * TS, k0 = bj * TS;
+    const int row = r0 + 2 * lr;
+
+    // current tile: registers -> LDS (the only place that waits for its loads)
+    if (tid < 2 * TS) {
+      const int rr = (tid < TS ? r0 : k0) + (tid & 63);
+      const double xv = (rr >= first && rr < n) ? (rr == first ? 1.0 : cx * h.scale) : 0.0;
+      if (tid < TS) xi[tid] = xv; else xj[tid - TS] = xv;
+    }
+    {
+      const bool r0ok = row >= first && row < n, r1ok = row + 1 >= first && row + 1 < n;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int kk = kq + 8 * p;
+        const int col = k0 + kk;
+        const bool cok = col >= first && col < n;
+        double2 d2;
+        d2.x = (r0ok && cok) ? c0[p] : 0.0;
+        d2.y = (r1ok && cok) ? c1[p] : 0.0;
+        *reinterpret_cast<double2*>(&T[2 * lr + kk * LD]) = d2;
+      }
+    }
+    // next tile: its loads go into the registers just freed and fly during the multiplications below
+    // (always issued, tile index clamped, so no predicated-load merge; hipcc waits for them at the top of
+    // the next iteration, where nothing else is outstanding)
+    const int tn = t + (int)gridDim.x;
+    issue(min(tn, ntiles - 1), c0, c1, cx);
+    lds_barrier();
+
+    if (diag) {
+      // y[r] = sum_k Tsym[r,k] x[k], Tsym from the lower triangle only
+      double acc = 0.0;
+#pragma unroll 4
+      for (int kk = q * 16; kk < q * 16 + 16; ++kk) {
+        const double tv = (lane >= kk) ? T[lane + kk * LD] : T[kk + lane * LD];
+        acc += tv * xj[kk];
+      }
+      red[q][lane] = acc;
+      lds_barrier();
+      if (tid < TS && r0 + tid < n)
+        ws[L.ypart + (size_t)bj * n + r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    } else {
+      double acc = 0.0;
+#pragma unroll 4
+      for (int kk = q * 16; kk < q * 16 + 16; ++kk) acc += T[lane + kk * LD] * xj[kk];
+      red[q][lane] = acc;
+      lds_barrier();
+      if (tid < TS && r0 + tid < n)
+        ws[L.ypart + (size_t)bj * n + r0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      lds_barrier();
+      // transposed product: y_j[k] += sum_r T[r,k] x_i[r]
+      acc = 0.0;
+#pragma unroll 4
+      for (int rr = q * 16; rr < q * 16 + 16; ++rr) acc += T[rr + lane * LD] * xi[rr];
+      red[q][lane] = acc;
+      lds_barrier();
+      if (tid < TS && k0 + tid < n)
+        ws[L.ypart + (size_t)bi * n + k0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+
+    if (diag) {
+      // store v (explicit leading 1) for the back-transformation and into both panel copies
+      const int arow = r0 + lane;
+      const bool rv = arow >= first && arow < n;
+      if (tid < TS && rv) {
+        const double xv = xi[tid];
+        A[(size_t)c * n + arow] = xv;
+        VW[(size_t)i * n + arow] = xv;
+        WV[(size_t)(nb + i) * n + arow] = xv;
+      }
+      if (t == 0 && tid == 0) {
+        ws[L.e + c] = h.beta;
+        ws[L.tau + c] = h.tau;
+        ws[L.hscale] = h.scale;
+      }
+    }
+    lds_barrier();  // T / x / red are rewritten by the next tile
+    t = tn;
+  }
+}
+
+// ---- reduce partial products, apply panel corrections, scale by tau ---------------------------------------
+// Block = 64 absolute rows x 4 groups; the groups split the partner-block range (y) and the reflector
+// range (corrections) and meet in LDS, so the launch has ~n/64 blocks instead of n/256.
+__global__ __launch_bounds__(1024) void k_w_reduce(double* __restrict__ a_all, long long stride_a,
+                                                   double* __restrict__ ws_all, TriLayout L, int c,
+                                                   int j0) {
+  constexpr int NG = 16;
+  __shared__ double dots[8][128], part[NG][64];
+  const int n = L.n, nb = L.nb, i = c - j0;
+  const int nba = (n + 63) >> 6, b0 = first_block(c + 1);
+  const double* A = a_all + (size_t)blockIdx.y * stride_a;
+  double* ws = ws_all + (size_t)blockIdx.y * L.slab;
+  double* VW = ws + L.vw;
+  double* WV = ws + L.wv;
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  {
+    const int col = tid & 127, part8 = tid >> 7;   // 8 slices of the block range per dot column
+    const int p = col < nb ? col : col - nb;
     double s = 0.0;
     if (p < i)
-      for (int b = 0; b < nt; ++b) s += ws[L.dpart + (size_t)b * 2 * nb + tid];
-    dots[tid] = s;  // dots[p] = V_p^T v, dots[nb+p] = W_p^T v
+      for (int b = first_block(c) + part8; b < nba; b += 8) s += ws[L.dpart + (size_t)b * 2 * nb + col];
+    dots[part8][col] = s;  // partial sums over rows >= c+2 of V[r,p] a[r] / W[r,p] a[r] (k_col_update)
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int p = tid < nb ? tid : tid - nb;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += dots[q][tid];
+    // v = (1, scale * a[c+2:]):  [p] = V_p^T v, [nb+p] = W_p^T v
+    dots[0][tid] = p < i ? ws[L.hscale] * s + VW[(size_t)tid * n + c + 1] : 0.0;
   }
   __syncthreads();
 
-  const double tau = ws[L.tau + c];
-  const int rr = blockIdx.x * 256 + tid;
-  double wv = 0.0;
-  if (rr < m) {
-    const size_t row = (size_t)c + 1 + rr;
-    double y = 0.0;
-    for (int o = 0; o < nt; ++o) y += ws[L.ypart + (size_t)o * n + rr];
-    for (int p = 0; p < i; ++p) {
-      const double v = VW[(size_t)p * n + row];
-      const double w = VW[(size_t)(nb + p) * n + row];
-      y -= v * dots[nb + p] + w * dots[p];
+  const int r = (b0 + blockIdx.x) * 64 + lane;
+  const bool valid = r >= c + 1 && r < n;
+  double acc = 0.0;
+  if (valid) {
+    for (int o = b0 + g; o < nba; o += NG) acc += ws[L.ypart + (size_t)o * n + r];
+    for (int p = g; p < i; p += NG) {
+      const double v = VW[(size_t)p * n + r];
+      const double w = VW[(size_t)(nb + p) * n + r];
+      acc -= v * dots[0][nb + p] + w * dots[0][p];
     }
-    const double wt = tau * y;
-    VW[(size_t)(nb + i) * n + row] = wt;
-    WV[(size_t)i * n + row] = wt;
-    wv = wt * A[(size_t)c * n + row];  // v was stored in A[:, c] by k_symv_tiles
   }
-  const double s = block_sum_bcast(wv, red);
-  if (tid == 0) ws[L.wvpart + blockIdx.x] = s;
+  part[g][lane] = acc;
+  __syncthreads();
+  if (g == 0) {
+    double wv = 0.0;
+    if (valid) {
+      double y = 0.0;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) y += part[q][lane];
+      const double wt = ws[L.tau + c] * y;
+      VW[(size_t)(nb + i) * n + r] = wt;
+      WV[(size_t)i * n + r] = wt;
+      wv = wt * A[(size_t)c * n + r];  // v was stored in A[:, c] by k_symv_tiles
+    }
+    wv = wave_sum(wv);
+    if (lane == 0) ws[L.wvpart + blockIdx.x] = wv;
+  }
 }
 
 // ---- end of panel: apply the pending alpha2 of the panel's last reflector --------------------------------------
 __global__ __launch_bounds__(256) void k_w_fix(double* __restrict__ ws_all, TriLayout L, int c, int j0) {
   const int n = L.n, nb = L.nb, i = c - j0;
-  const int m = n - c - 1;
+  const int nba = (n + 63) >> 6;
   double* ws = ws_all + (size_t)blockIdx.y * L.slab;
   double* VW = ws + L.vw;
   double* WV = ws + L.wv;
+  __shared__ double sh[4];
   const double tau = ws[L.tau + c];
-  if (tau == 0.0) return;
-  const double alpha2 = -0.5 * tau * sum_partials(ws + L.wvpart, (m + 255) / 256);
-  const int rr = blockIdx.x * 256 + threadIdx.x;
-  if (rr < m) {
-    const size_t row = (size_t)c + 1 + rr;
-    const double w = VW[(size_t)(nb + i) * n + row] + alpha2 * VW[(size_t)i * n + row];
-    VW[(size_t)(nb + i) * n + row] = w;
-    WV[(size_t)i * n + row] = w;
+  if (tau == 0.0) return;  // block-uniform
+  const double alpha2 = -0.5 * tau * sum_partials(ws + L.wvpart, nba - first_block(c + 1), sh);
+  const int r = c + 1 + blockIdx.x * 256 + threadIdx.x;
+  if (r < n) {
+    const double w = VW[(size_t)(nb + i) * n + r] + alpha2 * VW[(size_t)i * n + r];
+    VW[(size_t)(nb + i) * n + r] = w;
+    WV[(size_t)i * n + r] = w;
   }
 }
 
@@ -331,6 +452,8 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
                     float* ms_syr2k) {
   hipStream_t st = ctx->stream;
   const int nb = L.nb;
+  // persistent SYMV grid: 4 resident blocks per CU (LDS-limited), shared by the matrices of the batch
+  const int symv_blocks = 4 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
   {
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)batch);
     hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 8), 0, st, d_a, stride_a, n);
@@ -347,15 +470,20 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
     const int pend = j0 + nb < n ? j0 + nb : n;
     hipLaunchKernelGGL(k_zero_panels, dim3(64, (unsigned)batch), dim3(256), 0, st, d_ws, L);
     for (int c = j0; c < pend; ++c) {
-      const int rows = n - c;
-      hipLaunchKernelGGL(k_col_update, dim3((unsigned)((rows + 255) / 256), (unsigned)batch), dim3(256),
+      const int nba = (n + 63) / 64;
+      hipLaunchKernelGGL(k_col_update, dim3((unsigned)(nba - c / 64), (unsigned)batch), dim3(1024),
                          0, st, d_a, stride_a, d_ws, L, c, j0);
       if (c <= n - 3) {
-        const int m = n - c - 1;
-        const int nt = (m + 63) / 64;
+        const int nt = nba - (c + 1) / 64;
         if (prof) SC_HIP(ctx, hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)batch),
-                           dim3(256), 0, st, d_a, stride_a, d_ws, L, c, j0);
+        const int ntiles = nt * (nt + 1) / 2;
+        const int gx = std::min(ntiles, std::max(256, symv_blocks / batch));
+        if (n % 2 == 0)
+          hipLaunchKernelGGL(k_symv_tiles<true>, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_a,
+                             stride_a, d_ws, L, c, j0, ntiles);
+        else
+          hipLaunchKernelGGL(k_symv_tiles<false>, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_a,
+                             stride_a, d_ws, L, c, j0, ntiles);
         if (prof) {
           SC_HIP(ctx, hipEventRecord(ev[1], st));
           SC_HIP(ctx, hipEventSynchronize(ev[1]));
@@ -363,7 +491,7 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
           SC_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
           *ms_symv += ms;
         }
-        hipLaunchKernelGGL(k_w_reduce, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0,
+        hipLaunchKernelGGL(k_w_reduce, dim3((unsigned)nt, (unsigned)batch), dim3(1024), 0,
                            st, d_a, stride_a, d_ws, L, c, j0);
       }
     }
