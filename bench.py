@@ -41,6 +41,23 @@ def symv_algorithmic_bytes(n):
     return float(np.sum(m * (m + 1) / 2) * 8.0)
 
 
+def symv_traffic_per_launch(n, batch):
+    """
+    HBM bytes per k_symv_tiles launch from the PMC pass committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE in its own run, x2 gfx950 correction for 16-B-per-lane reads; see that file for the command).
+    Only valid for the matrix order it was collected at; None otherwise.
+    """
+    path = os.path.join(ROOT, "profiles", "r01_symv_pmc_fetch_size.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if int(d["n"]) != int(n):
+            return None
+        return round(float(d["hbm_read_bytes_per_launch_per_matrix_corrected"]) * batch)
+    except Exception:
+        return None
+
+
 def synthetic_coords(n_atoms, seeds):
     # the reference's own generator (tests/test_interaction.py:80-84), density 0.008 A^-3
     box = 5.0 * n_atoms ** (1.0 / 3.0)
@@ -80,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--structures-per-gpu", type=int, default=4)
+    ap.add_argument("--structures-per-gpu", type=int, default=8)
     ap.add_argument("--n-atoms", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -149,7 +166,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": symv_traffic_per_launch(n, B),
             "launches_per_step": launches,
             "algorithmic_bytes_per_launch": round(bytes_per_launch),
             "avg_launch_ms": round(avg_ms, 5),

@@ -1,98 +1,94 @@
 // Back-transformation  Z <- Q_H Z  (stage K7): applies the Householder reflectors of the
-// tridiagonalisation, NBT at a time, as compact-WY block reflectors  I - V T V^T  so that all O(n^3)
+// tridiagonalisation, NBT = 128 at a time, as compact-WY block reflectors  I - V T V^T  so that all O(n^3)
 // work is f64-MFMA GEMM (the role of LAPACK dormtr inside np.linalg.eigh, reference call site nma.py:61).
 //
-// Per block of reflectors (last block first):
-//   k_bt_extract   clean copy of V (zeros above the unit diagonal; A's storage there holds other data)
-//   GEMM (split-K) G  = V^T V                         (NBT x NBT)
-//   k_bt_tfactor   T  from tau and G  (dlarft recurrence, forward / columnwise)
-//   GEMM (split-K) W1 = V^T Z[rows]                   (NBT x n, K = rows: split so the grid fills the chip)
-//   k_bt_apply_t   W2 = T * sum_slices(W1)
-//   GEMM           Z[rows] -= V W2
+// Everything that does not depend on Z is done once, for ALL blocks, in four launches:
+//   k_bt_clean      zero, in place, the entries of A above each reflector's unit entry inside its block (A is
+//                   scratch by now), so V_p is a plain sub-matrix view of A
+//   GEMM (grouped, split-K)   G_p = V_p^T V_p
+//   k_bt_tfactor    T_p from tau and G_p (dlarft recurrence, forward / columnwise), one workgroup per block
+//   GEMM (grouped)  VT_p = V_p T_p
+// and then, last block first, three launches per block:
+//   GEMM (split-K)  W1 = V_p^T Z[rows]        (NBT x n, K = rows: split so the grid fills the chip)
+//   k_bt_sum        W  = sum of the K slices
+//   GEMM            Z[rows] -= VT_p W
+#include <algorithm>
 #include <vector>
 
 #include "eigh_internal.h"
 
 namespace {
 
-__global__ void k_bt_extract(const double* __restrict__ a_all, long long stride_a, double* __restrict__ bt_all,
-                             BtLayout BL, int cs, int kk) {
-  const int n = BL.n;
-  const double* A = a_all + (size_t)blockIdx.z * stride_a;
-  double* vc = bt_all + (size_t)blockIdx.z * BL.slab + BL.vc;
-  const int q = blockIdx.y;
-  const int mrow = n - cs - 1;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= mrow) return;
-  double v = 0.0;
-  if (q < kk && r >= q) v = A[(size_t)(cs + q) * n + (cs + 1 + r)];
-  vc[(size_t)q * n + r] = v;
+constexpr int kNbt = 128;
+constexpr int kGramSplits = 4;
+
+__global__ __launch_bounds__(256) void k_bt_clean(double* __restrict__ a_all, long long stride_a, int n,
+                                                  int nbt, int nref) {
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  const int cs = blockIdx.x * nbt;
+  // (a) triangle above the unit entries: rows cs+1 .. c of column c, for c in the block
+  for (int idx = threadIdx.x; idx < nbt * nbt; idx += blockDim.x) {
+    const int q = idx / nbt, rr = idx % nbt;  // column cs+q, row cs+1+rr
+    const int c = cs + q, r = cs + 1 + rr;
+    if (c < n && r < n && r <= c) A[(size_t)c * n + r] = 0.0;
+  }
+  // (b) columns without a reflector (c >= nref = n-2): zero rows cs+1 ..
+  for (int c = std::max(cs, nref); c < std::min(cs + nbt, n); ++c)
+    for (int r = cs + 1 + threadIdx.x; r < n; r += blockDim.x) A[(size_t)c * n + r] = 0.0;
 }
 
-// T (upper triangular, nbt x nbt, column-major ld nbt) from the Gram matrix slices and tau.
+// T (upper triangular, nbt x nbt, column-major) from the Gram slices and tau; grid (block, matrix).
 __global__ __launch_bounds__(256) void k_bt_tfactor(const double* __restrict__ tri_all, TriLayout TL,
-                                                    double* __restrict__ bt_all, BtLayout BL, int cs, int kk) {
+                                                    double* __restrict__ bt_all, BtLayout BL, int nref) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int nbt = BL.nbt;
-  double* G = sm;               // nbt x nbt
-  double* T = sm + nbt * nbt;   // nbt x nbt
-  const double* tri = tri_all + (size_t)blockIdx.x * TL.slab;
-  double* bt = bt_all + (size_t)blockIdx.x * BL.slab;
+  double* T = sm;               // nbt x nbt
+  double* gcol = sm + nbt * nbt;
+  const int p = blockIdx.x;
+  const double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  double* bt = bt_all + (size_t)blockIdx.y * BL.slab;
+  const double* gram = bt + BL.gram + (size_t)p * BL.splits_g * nbt * nbt;
+  const int cs = p * nbt;
+  const int kk = std::min(nbt, nref - cs);
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) {
-    double s = 0.0;
-    for (int sl = 0; sl < BL.splits_g; ++sl) s += bt[BL.gram + (size_t)sl * nbt * nbt + idx];
-    G[idx] = s;
-    T[idx] = 0.0;
-  }
+  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) T[idx] = 0.0;
   __syncthreads();
   for (int q = 0; q < kk; ++q) {
-    const double tau = tri[TL.tau + cs + q];
-    // T[0:q, q] = -tau * T[0:q, 0:q] * G[0:q, q]
     if (tid < q) {
       double s = 0.0;
-      for (int l = tid; l < q; ++l) s += T[tid + l * nbt] * G[l + q * nbt];
+      for (int sl = 0; sl < BL.splits_g; ++sl) s += gram[(size_t)sl * nbt * nbt + (size_t)q * nbt + tid];
+      gcol[tid] = s;   // G[tid, q] = v_tid . v_q
+    }
+    __syncthreads();
+    const double tau = tri[TL.tau + cs + q];
+    if (tid < q) {
+      // T[0:q, q] = -tau * T[0:q, 0:q] * G[0:q, q]
+      double s = 0.0;
+      for (int l = tid; l < q; ++l) s += T[tid + l * nbt] * gcol[l];
       T[tid + q * nbt] = -tau * s;
     }
     if (tid == q) T[q + q * nbt] = tau;
     __syncthreads();
   }
-  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) bt[BL.t + idx] = T[idx];
+  double* tout = bt + BL.t + (size_t)p * nbt * nbt;
+  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) tout[idx] = T[idx];
 }
 
-// W2[:, j] = T * sum_s W1_s[:, j]
-__global__ __launch_bounds__(256) void k_bt_apply_t(double* __restrict__ bt_all, BtLayout BL, int splits) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int nbt = BL.nbt, n = BL.n;
-  double* T = sm;                 // nbt x nbt
-  double* X = sm + nbt * nbt;     // nbt x cols_per_block
+__global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtLayout BL, int splits) {
   double* bt = bt_all + (size_t)blockIdx.y * BL.slab;
-  const int cols_per_block = blockDim.x / nbt;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) T[idx] = bt[BL.t + idx];
-  const int i = tid % nbt, cl = tid / nbt;
-  const int j = blockIdx.x * cols_per_block + cl;
-  double x = 0.0;
-  if (j < n)
-    for (int s = 0; s < splits; ++s) x += bt[BL.w1 + (size_t)s * nbt * n + (size_t)j * nbt + i];
-  X[cl * nbt + i] = x;
-  __syncthreads();
-  if (j < n) {
-    double acc = 0.0;
-    for (int l = i; l < nbt; ++l) acc += T[i + l * nbt] * X[cl * nbt + l];
-    bt[BL.w2 + (size_t)j * nbt + i] = acc;
+  const size_t total = (size_t)BL.nbt * BL.n;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int sl = 0; sl < splits; ++sl) s += bt[BL.w1 + (size_t)sl * total + idx];
+    bt[BL.w2 + idx] = s;
   }
 }
 
-constexpr int kNbt = 64;
-
-int splits_for(int n, int mrow) {
+int w1_splits_for(int n, int batch) {
   const int col_tiles = (n + 127) / 128;
-  int s = (640 + col_tiles - 1) / col_tiles;
-  const int cap = mrow / 128 > 1 ? mrow / 128 : 1;
-  if (s > cap) s = cap;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : s;
+  int s = (768 + col_tiles * batch - 1) / (col_tiles * batch);
+  return std::max(1, std::min(8, s));
 }
 
 }  // namespace
@@ -101,13 +97,14 @@ size_t bt_slab_doubles(int n, BtLayout* out) {
   BtLayout L{};
   L.n = n;
   L.nbt = kNbt;
-  L.splits = splits_for(n, n);
-  L.splits_g = 32;
+  L.splits = 8;
+  L.splits_g = kGramSplits;
+  const long long npanels = std::max(1, (std::max(n - 2, 0) + kNbt - 1) / kNbt);
   long long off = 0;
   auto take = [&](long long cnt) { long long o = off; off += (cnt + 7) / 8 * 8; return o; };
-  L.vc = take((long long)n * kNbt);
-  L.gram = take((long long)L.splits_g * kNbt * kNbt);
-  L.t = take((long long)kNbt * kNbt);
+  L.vc = 0;
+  L.gram = take(npanels * L.splits_g * kNbt * kNbt);
+  L.t = take(npanels * kNbt * kNbt);
   L.w1 = take((long long)L.splits * kNbt * n);
   L.w2 = take((long long)kNbt * n);
   L.slab = off;
@@ -115,74 +112,81 @@ size_t bt_slab_doubles(int n, BtLayout* out) {
   return (size_t)off;
 }
 
-int backtransform_batched(sc_ctx* ctx, const double* d_a, long long stride_a, int n, int batch,
-                          const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws, const BtLayout& BL,
-                          double* d_z, long long stride_z, GemmDesc* d_descs) {
+int bt_desc_count(int n, int batch) {
+  const int nref = std::max(n - 2, 0);
+  const int npanels = (nref + kNbt - 1) / kNbt;
+  return npanels * 4 * batch;
+}
+
+// d_a is modified (cleaned); d_vt: (batch, n, n) scratch that receives V T.
+int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, const double* d_tri_ws,
+                          const TriLayout& TL, double* d_bt_ws, const BtLayout& BL, double* d_z,
+                          long long stride_z, double* d_vt, GemmDesc* d_descs) {
   hipStream_t st = ctx->stream;
   const int nref = n - 2;  // reflector columns 0 .. n-3
   if (nref <= 0) return SC_OK;
   const int nbt = BL.nbt;
   const int npanels = (nref + nbt - 1) / nbt;
+  const int w1s = std::min(BL.splits, w1_splits_for(n, batch));
 
-  // descriptors: per panel [gram | w1 | update] x batch
-  std::vector<GemmDesc> h((size_t)npanels * 3 * batch);
-  std::vector<int> w1_splits(npanels), g_splits(npanels);
+  // descriptor table: [gram | vt | w1 | update] x npanels x batch  (each group contiguous for one launch)
+  const size_t grp = (size_t)npanels * batch;
+  std::vector<GemmDesc> h(4 * grp);
   for (int p = 0; p < npanels; ++p) {
     const int cs = p * nbt;
     const int mrow = n - cs - 1;
-    w1_splits[p] = std::min(BL.splits, splits_for(n, mrow));
-    g_splits[p] = std::max(1, std::min(BL.splits_g, mrow / 128));
+    const int pc = std::min(nbt, n - cs);   // columns of this block that exist in the matrix
     for (int b = 0; b < batch; ++b) {
       double* bt = d_bt_ws + (size_t)b * BL.slab;
-      double* vc = bt + BL.vc;
-      GemmDesc G{};
-      G.a = vc; G.sa_i = n; G.sa_k = 1;
-      G.b = vc; G.sb_k = 1; G.sb_j = n;
-      G.c = bt + BL.gram; G.ldc = nbt;
-      G.m = nbt; G.n = nbt; G.k = mrow;
+      const double* vp = d_a + (size_t)b * stride_a + (size_t)cs * n + cs + 1;
+      double* vtp = d_vt + (size_t)b * stride_a + (size_t)cs * n + cs + 1;
+      double* tp = bt + BL.t + (size_t)p * nbt * nbt;
+      GemmDesc G{};   // G_p = V^T V, split-K slices
+      G.a = vp; G.sa_i = n; G.sa_k = 1;
+      G.b = vp; G.sb_k = 1; G.sb_j = n;
+      G.c = bt + BL.gram + (size_t)p * BL.splits_g * nbt * nbt; G.ldc = nbt;
+      G.m = pc; G.n = pc; G.k = mrow;
       G.alpha = 1.0; G.beta = 0.0;
       G.split_stride = (long long)nbt * nbt;
-      h[((size_t)p * 3 + 0) * batch + b] = G;
-      GemmDesc W{};
-      W.a = vc; W.sa_i = n; W.sa_k = 1;
+      h[0 * grp + (size_t)p * batch + b] = G;
+      GemmDesc V{};   // VT_p = V T
+      V.a = vp; V.sa_i = 1; V.sa_k = n;
+      V.b = tp; V.sb_k = 1; V.sb_j = nbt;
+      V.c = vtp; V.ldc = n;
+      V.m = mrow; V.n = pc; V.k = pc;
+      V.alpha = 1.0; V.beta = 0.0;
+      h[1 * grp + (size_t)p * batch + b] = V;
+      GemmDesc W{};   // W1 = V^T Z[rows], split-K slices
+      W.a = vp; W.sa_i = n; W.sa_k = 1;
       W.b = d_z + (size_t)b * stride_z + cs + 1; W.sb_k = 1; W.sb_j = n;
       W.c = bt + BL.w1; W.ldc = nbt;
-      W.m = nbt; W.n = n; W.k = mrow;
+      W.m = pc; W.n = n; W.k = mrow;
       W.alpha = 1.0; W.beta = 0.0;
       W.split_stride = (long long)nbt * n;
-      h[((size_t)p * 3 + 1) * batch + b] = W;
-      GemmDesc U{};
-      U.a = vc; U.sa_i = 1; U.sa_k = n;
+      h[2 * grp + (size_t)p * batch + b] = W;
+      GemmDesc U{};   // Z[rows] -= VT W
+      U.a = vtp; U.sa_i = 1; U.sa_k = n;
       U.b = bt + BL.w2; U.sb_k = 1; U.sb_j = nbt;
       U.c = d_z + (size_t)b * stride_z + cs + 1; U.ldc = n;
-      U.m = mrow; U.n = n; U.k = nbt;
+      U.m = mrow; U.n = n; U.k = pc;
       U.alpha = -1.0; U.beta = 1.0;
-      h[((size_t)p * 3 + 2) * batch + b] = U;
+      h[3 * grp + (size_t)p * batch + b] = U;
     }
   }
   SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
 
+  hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
+                     nref);
+  SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, 0, BL.splits_g));
+  hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)npanels, (unsigned)batch), dim3(256),
+                     sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
+  SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, 0));
+
   for (int p = npanels - 1; p >= 0; --p) {
-    const int cs = p * nbt;
-    const int kk = std::min(nbt, nref - cs);
-    const int mrow = n - cs - 1;
-    hipLaunchKernelGGL(k_bt_extract, dim3((unsigned)((mrow + 255) / 256), (unsigned)nbt, (unsigned)batch),
-                       dim3(256), 0, st, d_a, stride_a, d_bt_ws, BL, cs, kk);
-    const GemmDesc* dp = d_descs + (size_t)p * 3 * batch;
-    SC_TRY(launch_gemm_f64(ctx, dp, batch, nbt, nbt, 1, g_splits[p]));
-    {
-      BtLayout B2 = BL;
-      B2.splits_g = g_splits[p];
-      hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)batch), dim3(256), sizeof(double) * 2 * nbt * nbt, st,
-                         d_tri_ws, TL, d_bt_ws, B2, cs, kk);
-    }
-    SC_TRY(launch_gemm_f64(ctx, dp + batch, batch, nbt, n, 1, w1_splits[p]));
-    {
-      const int cols_per_block = 256 / nbt;
-      hipLaunchKernelGGL(k_bt_apply_t, dim3((unsigned)((n + cols_per_block - 1) / cols_per_block), (unsigned)batch),
-                         dim3(256), sizeof(double) * (nbt * nbt + 256), st, d_bt_ws, BL, w1_splits[p]);
-    }
-    SC_TRY(launch_gemm_f64(ctx, dp + 2 * (size_t)batch, batch, mrow, n, 0));
+    const int mrow = n - p * nbt - 1;
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, n, 0, w1s));
+    hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s);
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, n, 0));
   }
   SC_HIP(ctx, hipGetLastError());
   SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload

@@ -56,8 +56,7 @@ Plan make_plan(int n, int batch, bool vectors) {
     P.off_qtmp = take((size_t)n * n * 8 * batch);
     P.off_u = take((size_t)n * n * 8 * batch);
     P.n_merge = dc_max_nodes(n, P.DL.leaf_max) * batch;
-    const int nref = n - 2 > 0 ? n - 2 : 0;
-    P.n_bt = ((nref + P.BL.nbt - 1) / P.BL.nbt) * 3 * batch;
+    P.n_bt = bt_desc_count(n, batch);
   }
   P.off_desc = take(sizeof(GemmDesc) * ((size_t)P.n_syr2k + P.n_merge + P.n_bt + 8));
   P.total = off;
@@ -186,7 +185,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a,
+    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, q_tmp,
                                  descs + P.n_syr2k + P.n_merge));
   }
   if (prof) {

@@ -71,15 +71,17 @@ int sturm_bisect_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, 
 struct BtLayout {
   int n, nbt, splits;
   long long slab;
-  long long vc;     // clean panel copy, n x nbt
-  long long gram;   // split-K slabs of V^T V: splits_g x nbt x nbt
-  long long t;      // nbt x nbt triangular factor
+  long long vc;     // (unused)
+  long long gram;   // per block: split-K slabs of V^T V, splits_g x nbt x nbt
+  long long t;      // per block: nbt x nbt triangular factor
   long long w1;     // split-K slabs of V^T Z: splits x nbt x n
   long long w2;     // T * sum(w1): nbt x n
   int splits_g;
 };
 size_t bt_slab_doubles(int n, BtLayout* out);
-int backtransform_batched(sc_ctx* ctx, const double* d_a, long long stride_a, int n, int batch,
+int bt_desc_count(int n, int batch);
+// d_a is modified (cleaned in place); d_vt: (batch, n, n) scratch that receives V T.
+int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch,
                           const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws,
-                          const BtLayout& BL, double* d_z, long long stride_z,
-                          GemmDesc* d_descs /* 3 * batch scratch records */);
+                          const BtLayout& BL, double* d_z, long long stride_z, double* d_vt,
+                          GemmDesc* d_descs /* bt_desc_count(n, batch) records */);
