@@ -135,12 +135,22 @@ int sc_hessian_from_pairs_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms,
  * w: (n,) ascending eigenvalues.  v: NULL (values only) or (n,n), rows = modes (nma.py:63). */
 int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v);
 
+/* Partial spectrum (no reference counterpart: np.linalg.eigh always returns all n pairs; this is the path of
+ * BASELINE config 5, "lowest 100 modes only").  Eigenvalues with ascending index il..iu (0-based, inclusive):
+ * w: (m,), v: NULL or (m,n) rows = modes, m = iu - il + 1.  Bisection + inverse iteration on the tridiagonal
+ * matrix, back-transformation of the selected vectors only. */
+int sc_eigh_range_f64(sc_ctx* ctx, const double* a, int64_t n, int64_t il, int64_t iu, double* w, double* v);
+
 /* Fused: coordinates -> Hessian (device) -> eigenpairs, no host round trip of the matrix.
  * Replaces ANM(coord, ff).eigen() (anm.py:150-167 -> nma.py:29-63) for built-in force fields. */
 int sc_anm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
                      const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v);
 int sc_gnm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
                      const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w, double* v);
+/* Same, partial spectrum il..iu of the 3n x 3n Hessian (w: (m,), v: NULL or (m, 3n)). */
+int sc_anm_eigen_range_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,
+                           const sc_patch_desc* patch, const double* inv_sqrt_mass, int64_t il, int64_t iu,
+                           double* w, double* v);
 
 /* ---- device-resident / batched entry points (bench + multi-structure sharding) ------------
  * All pointers are device pointers on the context's device.  Work is enqueued on the context's
@@ -157,6 +167,10 @@ int sc_dev_hessian_f64(sc_ctx* ctx, const double* d_coord, int64_t n_atoms, int6
  * d_a: (batch,n,n), lower triangle read, DESTROYED (used as workspace).
  * d_w: (batch,n).  d_v: NULL or (batch,n,n) rows = modes. */
 int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
+
+/* Partial spectrum of `batch` matrices: d_w (batch, m), d_v NULL or (batch, m, n). d_a is destroyed. */
+int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
+                          double* d_w, double* d_v);
 
 /* Bytes of device workspace sc_dev_eigh_f64 will hold for (n, batch) (allocated lazily, cached). */
 int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors);

@@ -97,7 +97,7 @@ class ElasticNetworkModel:
         self._matrix = None
 
     # ---- eigensolve ---------------------------------------------------------------------------
-    def _eigen_device(self):
+    def _eigen_device(self, subset_by_index=None):
         """
         (eig_values, eig_vectors[rows]) on the device.  When the matrix has not been materialised
         on the host and the force field is evaluated on device, assembly and eigensolve are fused
@@ -105,6 +105,31 @@ class ElasticNetworkModel:
         matrix (possibly user-assigned, anm.py:120-130) is solved as it is.
         """
         from . import nma
+
+        if subset_by_index is not None:
+            lo, hi = (int(x) for x in subset_by_index)
+            if self._matrix is None and self._covariance is None and self._dim == 3:
+                ff_desc, patch, fused = device_plan(self._ff)
+                if fused:
+                    coord = _validated_coord(self._coord, self._ff)
+                    n = len(coord)
+                    if not (0 <= lo <= hi < 3 * n):
+                        raise ValueError(f"subset_by_index {subset_by_index} out of range for order {3 * n}")
+                    keep = []
+                    patch_desc = _normalised_patch(patch, n, keep)
+                    pd = C.byref(patch_desc) if patch_desc is not None else None
+                    ctx = _hip.context()
+                    m = hi - lo + 1
+                    w = np.empty(m)
+                    v = np.empty((m, 3 * n))
+                    ism = None
+                    if self._inv_sqrt_mass is not None:
+                        ism = np.ascontiguousarray(self._inv_sqrt_mass, dtype=np.float64)
+                    ctx.check(_hip.lib().sc_anm_eigen_range_f64(
+                        ctx.handle, _hip.ptr(coord), n, C.byref(ff_desc), pd, _hip.ptr(ism), lo, hi,
+                        _hip.ptr(w), _hip.ptr(v)))
+                    return w, v
+            return nma.eigh(self._get_matrix(), subset_by_index=(lo, hi))
 
         if self._matrix is None and self._covariance is None:
             ff_desc, patch, fused = device_plan(self._ff)

@@ -55,12 +55,12 @@ class ANM(ElasticNetworkModel):
     def covariance(self, value):
         self._set_covariance(value)
 
-    def eigen(self):
+    def eigen(self, subset_by_index=None):
         """
         Eigenvalues (ascending, shape (3n,)) and eigenvectors (rows, shape (3n,3n)) of the
         Hessian; the first six belong to rigid-body motions (anm.py:150-167).
         """
-        return nma.eigen(self)
+        return nma.eigen(self, subset_by_index)
 
     def normal_mode(self, index, amplitude, frames, movement="sine"):
         """Displacements (frames, n, 3) animating mode ``index`` (anm.py:169-207)."""

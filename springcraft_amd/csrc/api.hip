@@ -451,6 +451,60 @@ int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v) {
   return SC_OK;
 }
 
+int sc_eigh_range_f64(sc_ctx* ctx, const double* a, int64_t n, int64_t il, int64_t iu, double* w, double* v) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n <= 0 || !a || !w || il < 0 || iu < il || iu >= n)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = iu - il + 1;
+  const size_t elems = (size_t)n * n;
+  SC_TRY(sc_reserve_scratch(ctx, elems * 8 + (size_t)m * 8 + (v ? (size_t)m * n * 8 : 0) + 4096));
+  Bump bump{(char*)ctx->scratch};
+  double* d_a = bump.take<double>(elems);
+  double* d_w = bump.take<double>((size_t)m);
+  double* d_v = v ? bump.take<double>((size_t)m * n) : nullptr;
+  SC_HIP(ctx, hipMemcpyAsync(d_a, a, elems * 8, hipMemcpyHostToDevice, ctx->stream));
+  SC_TRY(eigh_range_batched(ctx, d_a, n, 1, il, iu, d_w, d_v));
+  SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, (size_t)m * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_anm_eigen_range_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
+                           const sc_patch_desc* patch, const double* inv_sqrt_mass, int64_t il, int64_t iu,
+                           double* w, double* v) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  const int64_t dim3n = 3 * n;
+  if (n <= 0 || !w || il < 0 || iu < il || iu >= dim3n)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = iu - il + 1;
+  const size_t elems = (size_t)dim3n * dim3n;
+  Staged st;
+  Bump bump{};
+  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass,
+                      elems * 8 + (size_t)m * 8 + (v ? (size_t)m * dim3n * 8 : 0) + 4096, st, bump));
+  double* d_m = bump.take<double>(elems);
+  double* d_w = bump.take<double>((size_t)m);
+  double* d_v = v ? bump.take<double>((size_t)m * dim3n) : nullptr;
+  SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, st.has_patch ? &st.patch : nullptr, st.d_w, d_m));
+  SC_TRY(eigh_range_batched(ctx, d_m, dim3n, 1, il, iu, d_w, d_v));
+  SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, (size_t)m * dim3n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
+                          double* d_w, double* d_v) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n <= 0 || batch <= 0 || !d_a || !d_w) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  return eigh_range_batched(ctx, d_a, n, batch, il, iu, d_w, d_v);
+}
+
 static int enm_eigen_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
                           const sc_patch_desc* patch, const double* inv_sqrt_mass, double* w,
                           double* v, int dim) {

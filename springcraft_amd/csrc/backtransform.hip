@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void k_bt_tfactor(const double* __restrict__ t
   for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) tout[idx] = T[idx];
 }
 
-__global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtLayout BL, int splits) {
+__global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtLayout BL, int splits, int ncols) {
   double* bt = bt_all + (size_t)blockIdx.y * BL.slab;
-  const size_t total = (size_t)BL.nbt * BL.n;
+  const size_t total = (size_t)BL.nbt * ncols;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
     double s = 0.0;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtL
   }
 }
 
-int w1_splits_for(int n, int batch) {
-  const int col_tiles = (n + 127) / 128;
+int w1_splits_for(int ncols, int batch) {
+  const int col_tiles = (ncols + 127) / 128;
   int s = (768 + col_tiles * batch - 1) / (col_tiles * batch);
   return std::max(1, std::min(8, s));
 }
@@ -121,13 +121,13 @@ int bt_desc_count(int n, int batch) {
 // d_a is modified (cleaned); d_vt: (batch, n, n) scratch that receives V T.
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, const double* d_tri_ws,
                           const TriLayout& TL, double* d_bt_ws, const BtLayout& BL, double* d_z,
-                          long long stride_z, double* d_vt, GemmDesc* d_descs) {
+                          long long stride_z, int ncols, double* d_vt, GemmDesc* d_descs) {
   hipStream_t st = ctx->stream;
   const int nref = n - 2;  // reflector columns 0 .. n-3
   if (nref <= 0) return SC_OK;
   const int nbt = BL.nbt;
   const int npanels = (nref + nbt - 1) / nbt;
-  const int w1s = std::min(BL.splits, w1_splits_for(n, batch));
+  const int w1s = std::min(BL.splits, w1_splits_for(ncols, batch));
 
   // descriptor table: [gram | vt | w1 | update] x npanels x batch  (each group contiguous for one launch)
   const size_t grp = (size_t)npanels * batch;
@@ -160,15 +160,15 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       W.a = vp; W.sa_i = n; W.sa_k = 1;
       W.b = d_z + (size_t)b * stride_z + cs + 1; W.sb_k = 1; W.sb_j = n;
       W.c = bt + BL.w1; W.ldc = nbt;
-      W.m = pc; W.n = n; W.k = mrow;
+      W.m = pc; W.n = ncols; W.k = mrow;
       W.alpha = 1.0; W.beta = 0.0;
-      W.split_stride = (long long)nbt * n;
+      W.split_stride = (long long)nbt * ncols;
       h[2 * grp + (size_t)p * batch + b] = W;
       GemmDesc U{};   // Z[rows] -= VT W
       U.a = vtp; U.sa_i = 1; U.sa_k = n;
       U.b = bt + BL.w2; U.sb_k = 1; U.sb_j = nbt;
       U.c = d_z + (size_t)b * stride_z + cs + 1; U.ldc = n;
-      U.m = mrow; U.n = n; U.k = pc;
+      U.m = mrow; U.n = ncols; U.k = pc;
       U.alpha = -1.0; U.beta = 1.0;
       h[3 * grp + (size_t)p * batch + b] = U;
     }
@@ -184,9 +184,9 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
 
   for (int p = npanels - 1; p >= 0; --p) {
     const int mrow = n - p * nbt - 1;
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, n, 0, w1s));
-    hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s);
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, n, 0));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, 0, w1s));
+    hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, 0));
   }
   SC_HIP(ctx, hipGetLastError());
   SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload

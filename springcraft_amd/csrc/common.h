@@ -89,3 +89,6 @@ int launch_hessian_from_pairs(sc_ctx* ctx, const double* d_coord, int64_t n,
 // d_a: (batch, n, n) symmetric (destroyed), d_w: (batch, n), d_v: nullptr or (batch, n, n) rows = modes.
 int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
 size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors);
+// Partial spectrum: eigenvalues il..iu (0-based, inclusive): d_w (batch, m), d_v nullptr or (batch, m, n).
+int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
+                       double* d_w, double* d_v);

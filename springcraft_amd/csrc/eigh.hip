@@ -185,7 +185,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, q_tmp,
+    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
                                  descs + P.n_syr2k + P.n_merge));
   }
   if (prof) {
@@ -204,5 +204,71 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
   SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads
+  return SC_OK;
+}
+
+
+// ---- partial spectrum --------------------------------------------------------------------------------------
+int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, int64_t il64, int64_t iu64,
+                       double* d_w, double* d_v) {
+  if (n64 > 46000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "matrix order %lld too large", (long long)n64);
+  const int n = (int)n64, batch = (int)batch64, il = (int)il64, iu = (int)iu64;
+  if (il < 0 || iu < il || iu >= n)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad eigenvalue index range [%d, %d] for order %d", il, iu, n);
+  const int m = iu - il + 1;
+  hipStream_t st = ctx->stream;
+  const long long stride_a = (long long)n * n;
+
+  // workspace: tri slab | stein | bt slab | VT (n x n) | descriptors
+  TriLayout TL;
+  BtLayout BL;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t off_tri = take(tri_slab_doubles(n, &TL) * 8 * batch);
+  const int npanels = (n + kNb - 1) / kNb;
+  size_t off_stein = 0, off_bt = 0, off_vt = 0;
+  int n_bt = 0;
+  if (d_v) {
+    off_stein = take(stein_workspace_doubles(n, m) * 8 * batch);
+    off_bt = take(bt_slab_doubles(n, &BL) * 8 * batch);
+    off_vt = take((size_t)n * n * 8 * batch);
+    n_bt = bt_desc_count(n, batch);
+  }
+  const size_t n_desc = (size_t)npanels * batch + n_bt + 2 * (size_t)batch + 8;
+  const size_t off_desc = take(sizeof(GemmDesc) * n_desc);
+  SC_TRY(sc_reserve_ws(ctx, off));
+  char* base = (char*)ctx->ws;
+  double* tri_ws = (double*)(base + off_tri);
+  GemmDesc* descs = (GemmDesc*)(base + off_desc);
+
+  std::vector<GemmDesc> h((size_t)npanels * batch);
+  for (int p = 0; p < npanels; ++p) {
+    const int pend = std::min((p + 1) * kNb, n);
+    for (int b = 0; b < batch; ++b) {
+      double* ws = tri_ws + (size_t)b * TL.slab;
+      GemmDesc D{};
+      D.a = ws + TL.vw + pend; D.sa_i = 1; D.sa_k = n;
+      D.b = ws + TL.wv + pend; D.sb_k = n; D.sb_j = 1;
+      D.c = d_a + (size_t)b * stride_a + (size_t)pend * n + pend; D.ldc = n;
+      D.m = n - pend; D.n = n - pend; D.k = 2 * kNb;
+      D.alpha = -1.0; D.beta = 1.0;
+      D.lower_only = 1;
+      h[(size_t)p * batch + b] = D;
+    }
+  }
+  SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  float ms_symv = 0.f, ms_syr2k = 0.f;
+  SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_symv, &ms_syr2k));
+  GemmDesc* d2 = descs + (size_t)npanels * batch;
+  if (!d_v) {
+    SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, nullptr, 0, nullptr, d2));
+  } else {
+    const long long stride_x = (long long)n * m;
+    SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, d_v, stride_x, (double*)(base + off_stein), d2));
+    // the back-transformation indexes its scratch with the matrix stride: VT lives in an n x n buffer per matrix
+    SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, (double*)(base + off_bt), BL, d_v,
+                                 stride_x, m, (double*)(base + off_vt), d2 + 2 * batch));
+  }
+  SC_HIP(ctx, hipStreamSynchronize(st));
   return SC_OK;
 }

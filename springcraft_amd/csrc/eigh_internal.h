@@ -83,5 +83,11 @@ int bt_desc_count(int n, int batch);
 // d_a is modified (cleaned in place); d_vt: (batch, n, n) scratch that receives V T.
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch,
                           const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws,
-                          const BtLayout& BL, double* d_z, long long stride_z, double* d_vt,
+                          const BtLayout& BL, double* d_z, long long stride_z, int ncols, double* d_vt,
                           GemmDesc* d_descs /* bt_desc_count(n, batch) records */);
+
+// ---- partial spectrum (stein.hip) -----------------------------------------------------------------------
+size_t stein_workspace_doubles(int n, int m);
+int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const TriLayout& TL, int il, int iu,
+                  double* d_w, long long stride_w, double* d_x, long long stride_x, double* d_ws,
+                  GemmDesc* d_descs /* 2 * batch */);

@@ -49,9 +49,9 @@ class GNM(ElasticNetworkModel):
     def covariance(self, value):
         self._set_covariance(value)
 
-    def eigen(self):
+    def eigen(self, subset_by_index=None):
         """Eigenvalues (ascending, (n,)) and eigenvectors (rows, (n,n)) of the Kirchhoff matrix (gnm.py:145-158)."""
-        return nma.eigen(self)
+        return nma.eigen(self, subset_by_index)
 
     def frequencies(self):
         """Mode frequencies in arbitrary units (gnm.py:160-176)."""

@@ -23,17 +23,30 @@ K_B = 1.380649e-23
 N_A = 6.02214076e23
 
 
-def eigh(matrix, eigenvectors=True):
+def eigh(matrix, eigenvectors=True, subset_by_index=None):
     """
     Device replacement for ``np.linalg.eigh(matrix)`` as used at nma.py:61: ascending
     eigenvalues of a symmetric float64 matrix (lower triangle read) and, as ROWS, the
     corresponding eigenvectors (``eig_vectors[i]`` belongs to ``eig_values[i]``).
+
+    ``subset_by_index=(lo, hi)`` (inclusive, like ``scipy.linalg.eigh``) selects the partial-spectrum
+    path: only eigenpairs lo..hi are computed (bisection + inverse iteration), which is what large
+    models that only need their slowest modes should use.
     """
     a = np.ascontiguousarray(matrix, dtype=np.float64)
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError(f"Expected a square matrix, got shape {a.shape}")
     n = a.shape[0]
     ctx = _hip.context()
+    if subset_by_index is not None:
+        lo, hi = (int(x) for x in subset_by_index)
+        if not (0 <= lo <= hi < n):
+            raise ValueError(f"subset_by_index {subset_by_index} out of range for order {n}")
+        m = hi - lo + 1
+        w = np.empty(m, dtype=np.float64)
+        v = np.empty((m, n), dtype=np.float64) if eigenvectors else None
+        ctx.check(_hip.lib().sc_eigh_range_f64(ctx.handle, _hip.ptr(a), n, lo, hi, _hip.ptr(w), _hip.ptr(v)))
+        return (w, v) if eigenvectors else w
     w = np.empty(n, dtype=np.float64)
     v = np.empty((n, n), dtype=np.float64) if eigenvectors else None
     ctx.check(_hip.lib().sc_eigh_f64(ctx.handle, _hip.ptr(a), n, _hip.ptr(w), _hip.ptr(v)))
@@ -51,13 +64,14 @@ def _model_kind(enm):
     raise ValueError("Instance of GNM/ANM class expected.")
 
 
-def eigen(enm):
+def eigen(enm, subset_by_index=None):
     """
     Eigenvalues (ascending) and eigenvectors (rows) of the Kirchhoff / Hessian matrix of a
-    GNM / ANM (reference: nma.py:29-63).
+    GNM / ANM (reference: nma.py:29-63).  ``subset_by_index=(lo, hi)`` (extension, inclusive) restricts
+    the computation to modes lo..hi.
     """
     _model_kind(enm)
-    return enm._eigen_device()
+    return enm._eigen_device(subset_by_index)
 
 
 def frequencies(enm):

@@ -201,3 +201,67 @@ def test_consumers_run_on_device_eigen(sc):
     assert np.allclose(anm.hessian @ anm.covariance @ anm.hessian, anm.hessian)  # tests/test_anm.py:26-37
     with pytest.raises(ValueError):
         sc.nma.eigen(object())                                                # nma.py:58
+
+
+# ---- partial spectrum (K8; BASELINE config 5) ---------------------------------------------------------------
+
+@pytest.mark.parametrize("n,lo,hi", [(50, 0, 9), (200, 0, 29), (333, 100, 140), (1000, 0, 105), (64, 60, 63), (5, 0, 4)])
+def test_partial_spectrum_random(sc, n, lo, hi):
+    a = sym(np.random.RandomState(n + lo), n)
+    w, v = sc.nma.eigh(a, subset_by_index=(lo, hi))
+    w_ref, v_ref = np.linalg.eigh(a)
+    m = hi - lo + 1
+    assert w.shape == (m,) and v.shape == (m, n)
+    scale = np.abs(w_ref).max()
+    assert np.abs(w - w_ref[lo:hi + 1]).max() <= 1e-11 * scale
+    r = a @ v.T - v.T * w[None, :]
+    assert np.abs(r).max() <= 1e-9 * scale
+    assert np.abs(v @ v.T - np.eye(m)).max() <= 1e-10
+    w_only = sc.nma.eigh(a, eigenvectors=False, subset_by_index=(lo, hi))
+    assert np.abs(w_only - w_ref[lo:hi + 1]).max() <= 1e-11 * scale
+
+
+def test_partial_spectrum_degenerate_cluster(sc):
+    """ANM: the six rigid-body modes form a numerically degenerate cluster; compare the invariant subspace."""
+    coord = synthetic_coord(300, 9)
+    h, _ = orc.compute_hessian(coord, orc.invariant_ff(13.0))
+    anm = sc.ANM(coord, sc.InvariantForceField(13.0))
+    w, v = anm.eigen(subset_by_index=(0, 25))        # fused device path
+    w_ref, v_ref = np.linalg.eigh(h)
+    check_eigenvalues(np.concatenate([w, w_ref[26:]]), w_ref, 6)
+    assert np.abs(v @ v.T - np.eye(26)).max() <= 1e-9
+    p = v[:6].T @ v[:6]
+    p_ref = v_ref[:, :6] @ v_ref[:, :6].T
+    assert np.abs(p - p_ref).max() <= 1e-8                              # same null space
+    r = h @ v.T - v.T * w[None, :]
+    assert np.abs(r).max() <= 1e-9 * w_ref.max()
+    overlap = np.abs(np.sum(v[6:] * v_ref[:, 6:26].T, axis=1))
+    assert np.all(overlap >= 1 - 1e-6)
+    # identical matrix through the host-matrix route
+    w2, v2 = sc.nma.eigh(anm.hessian, subset_by_index=(0, 25))
+    assert np.abs(w2[6:] - w[6:]).max() <= 1e-10 * w_ref.max()
+
+
+def test_partial_spectrum_exactly_degenerate(sc):
+    a = np.eye(120) * 3.0
+    w, v = sc.nma.eigh(a, subset_by_index=(0, 19))
+    assert np.allclose(w, 3.0) and np.abs(v @ v.T - np.eye(20)).max() <= 1e-10
+
+
+def test_config5_anm_n8000_lowest_modes(sc):
+    """Config 5: N = 8000 C-alpha (24000 x 24000 Hessian), InvariantForceField 13 A, modes 0..105."""
+    import os
+    from tests.util import GOLDEN
+
+    path = os.path.join(GOLDEN, "generated", "c5_n8000_inv13.npz")
+    if not os.path.exists(path):
+        pytest.skip("c5 golden not generated")
+    g = np.load(path)
+    coord = synthetic_coord(8000, 0, 100.0)
+    w, v = sc.ANM(coord, sc.InvariantForceField(13.0)).eigen(subset_by_index=(0, 105))
+    ref = g["eigenvalues_low106"]
+    lam_scale = 100.0   # ||H|| ~ 1e2 for this cutoff; trivial modes are noise at 1e-13 of it
+    assert np.abs(w[:6]).max() <= 1e-9 * lam_scale
+    rel = np.abs(w[6:] - ref[6:]) / np.abs(ref[6:])
+    assert rel.max() <= 1e-5, rel.max()
+    assert np.abs(v @ v.T - np.eye(106)).max() <= 1e-8
