@@ -141,6 +141,12 @@ int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v);
  * matrix, back-transformation of the selected vectors only. */
 int sc_eigh_range_f64(sc_ctx* ctx, const double* a, int64_t n, int64_t il, int64_t iu, double* w, double* v);
 
+/* Hermitian pseudo-inverse, replaces np.linalg.pinv(M, hermitian=True, rcond=1e-6) in the covariance / matrix
+ * properties (anm.py:114-117,132-136; gnm.py:107-110,125-131): eigendecomposition on the device, then
+ * (U * s) U^T with s_i = 1/w_i where |w_i| > rcond * max|w| and 0 elsewhere (one f64-MFMA GEMM).
+ * a: (n,n) symmetric, lower triangle read, not modified; out: (n,n). */
+int sc_pinvh_f64(sc_ctx* ctx, const double* a, int64_t n, double rcond, double* out);
+
 /* Fused: coordinates -> Hessian (device) -> eigenpairs, no host round trip of the matrix.
  * Replaces ANM(coord, ff).eigen() (anm.py:150-167 -> nma.py:29-63) for built-in force fields. */
 int sc_anm_eigen_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, const sc_ff_desc* ff,

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "sc_hessian_f64", "sc_kirchhoff_from_pairs_f64", "sc_hessian_from_pairs_f64", "sc_eigh_f64",
     "sc_anm_eigen_f64", "sc_gnm_eigen_f64", "sc_dev_kirchhoff_f64", "sc_dev_hessian_f64",
     "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
-    "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64",
+    "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
 ]
 
 
@@ -114,6 +114,7 @@ def lib():
         "sc_dev_eigh_f64": (i32, [vp, vp, i64, i64, vp, vp]),
         "sc_eigh_workspace_bytes": (i64, [i64, i64, i32]),
         "sc_eigh_range_f64": (i32, [vp, vp, i64, i64, i64, vp, vp]),
+        "sc_pinvh_f64": (i32, [vp, vp, i64, dbl, vp]),
         "sc_anm_eigen_range_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, i64, i64, vp, vp]),
         "sc_dev_eigh_range_f64": (i32, [vp, vp, i64, i64, i64, i64, vp, vp]),
         "sc_ctx_set_profiling": (i32, [vp, i32]),

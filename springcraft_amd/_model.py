@@ -74,7 +74,9 @@ class ElasticNetworkModel:
             if self._covariance is None:
                 self._matrix, _ = _assemble(self._coord, self._ff, self._dim, self._inv_sqrt_mass)
             else:
-                self._matrix = np.linalg.pinv(self._covariance, hermitian=True, rcond=1e-6)
+                from . import nma
+
+                self._matrix = nma.pinvh(self._covariance, rcond=1e-6)
         return self._matrix
 
     def _set_matrix(self, value, error=IndexError):
@@ -86,7 +88,9 @@ class ElasticNetworkModel:
 
     def _get_covariance(self):
         if self._covariance is None:
-            self._covariance = np.linalg.pinv(self._get_matrix(), hermitian=True, rcond=1e-6)
+            from . import nma
+
+            self._covariance = nma.pinvh(self._get_matrix(), rcond=1e-6)
         return self._covariance
 
     def _set_covariance(self, value):

@@ -451,6 +451,23 @@ int sc_eigh_f64(sc_ctx* ctx, const double* a, int64_t n, double* w, double* v) {
   return SC_OK;
 }
 
+int sc_pinvh_f64(sc_ctx* ctx, const double* a, int64_t n, double rcond, double* out) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!a || !out))) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return SC_OK;
+  const size_t elems = (size_t)n * n;
+  SC_TRY(sc_reserve_scratch(ctx, 2 * elems * 8 + 4096));
+  Bump bump{(char*)ctx->scratch};
+  double* d_a = bump.take<double>(elems);
+  double* d_out = bump.take<double>(elems);
+  SC_HIP(ctx, hipMemcpyAsync(d_a, a, elems * 8, hipMemcpyHostToDevice, ctx->stream));
+  SC_TRY(pinvh_device(ctx, d_a, n, rcond, d_out));
+  SC_HIP(ctx, hipMemcpyAsync(out, d_out, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
 int sc_eigh_range_f64(sc_ctx* ctx, const double* a, int64_t n, int64_t il, int64_t iu, double* w, double* v) {
   if (!ctx) return SC_ERR_INVALID_ARG;
   if (n <= 0 || !a || !w || il < 0 || iu < il || iu >= n)

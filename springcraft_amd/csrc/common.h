@@ -92,3 +92,5 @@ size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors);
 // Partial spectrum: eigenvalues il..iu (0-based, inclusive): d_w (batch, m), d_v nullptr or (batch, m, n).
 int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
                        double* d_w, double* d_v);
+// Hermitian pseudo-inverse of the (n,n) matrix d_a (destroyed) into d_out, numpy.linalg.pinv(hermitian=True) rule.
+int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n, double rcond, double* d_out);

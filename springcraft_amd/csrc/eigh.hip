@@ -272,3 +272,50 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   SC_HIP(ctx, hipStreamSynchronize(st));
   return SC_OK;
 }
+
+
+// ---- Hermitian pseudo-inverse from the eigenpairs (F1: covariance) ------------------------------------------
+// np.linalg.pinv(M, hermitian=True, rcond) as used at anm.py:115,135 / gnm.py:108,128:
+//   M = U diag(w) U^T;  pinv = (U * s) U^T  with  s_i = 1/w_i if |w_i| > rcond * max|w| else 0.
+namespace {
+__global__ void k_pinv_scale(const double* __restrict__ q, const double* __restrict__ w, int n, double rcond,
+                             double* __restrict__ qs) {
+  __shared__ double s_cut;
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(w[i]));   // w is ascending: max |w| is at one of the ends
+    s_cut = rcond * mx;
+  }
+  __syncthreads();
+  const int col = blockIdx.x;
+  const double wi = w[col];
+  const double s = fabs(wi) > s_cut ? 1.0 / wi : 0.0;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) qs[(size_t)col * n + r] = q[(size_t)col * n + r] * s;
+}
+}  // namespace
+
+int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_out) {
+  const int n = (int)n64;
+  hipStream_t st = ctx->stream;
+  // buffers: w (n) | Q (n^2) | QS (n^2) | desc, carved from the scratch allocation behind d_out's caller
+  double *d_w, *d_q, *d_qs;
+  GemmDesc* d_desc;
+  SC_HIP(ctx, hipMalloc(&d_w, sizeof(double) * n));
+  SC_HIP(ctx, hipMalloc(&d_q, sizeof(double) * (size_t)n * n));
+  SC_HIP(ctx, hipMalloc(&d_qs, sizeof(double) * (size_t)n * n));
+  SC_HIP(ctx, hipMalloc(&d_desc, sizeof(GemmDesc)));
+  int rc = eigh_batched(ctx, d_a, n, 1, d_w, d_q);
+  if (rc == SC_OK) {
+    hipLaunchKernelGGL(k_pinv_scale, dim3((unsigned)n), dim3(256), 0, st, d_q, d_w, n, rcond, d_qs);
+    GemmDesc D{};
+    D.a = d_qs; D.sa_i = 1; D.sa_k = n;       // (U * s)
+    D.b = d_q; D.sb_k = n; D.sb_j = 1;        // U^T: B(k,j) = U[j, k]
+    D.c = d_out; D.ldc = n; D.m = n; D.n = n; D.k = n;
+    D.alpha = 1.0; D.beta = 0.0;
+    if (hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, st) != hipSuccess) rc = SC_ERR_HIP;
+    if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, 0);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;
+  }
+  (void)hipFree(d_w); (void)hipFree(d_q); (void)hipFree(d_qs); (void)hipFree(d_desc);
+  return rc;
+}

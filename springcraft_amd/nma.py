@@ -15,7 +15,7 @@ import numpy as np
 from . import _hip
 
 __all__ = [
-    "eigen", "eigh", "frequencies", "mean_square_fluctuation", "bfactor", "dcc",
+    "eigen", "eigh", "pinvh", "frequencies", "mean_square_fluctuation", "bfactor", "dcc",
     "normal_mode", "linear_response", "prs", "effector_sensor",
 ]
 
@@ -51,6 +51,21 @@ def eigh(matrix, eigenvectors=True, subset_by_index=None):
     v = np.empty((n, n), dtype=np.float64) if eigenvectors else None
     ctx.check(_hip.lib().sc_eigh_f64(ctx.handle, _hip.ptr(a), n, _hip.ptr(w), _hip.ptr(v)))
     return (w, v) if eigenvectors else w
+
+
+def pinvh(matrix, rcond=1e-6):
+    """
+    Device replacement for ``np.linalg.pinv(matrix, hermitian=True, rcond=rcond)`` as used by the
+    ``covariance`` / ``hessian`` / ``kirchhoff`` properties (anm.py:114-117,132-136; gnm.py:107-110,125-131).
+    """
+    a = np.ascontiguousarray(matrix, dtype=np.float64)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError(f"Expected a square matrix, got shape {a.shape}")
+    n = a.shape[0]
+    out = np.empty((n, n), dtype=np.float64)
+    ctx = _hip.context()
+    ctx.check(_hip.lib().sc_pinvh_f64(ctx.handle, _hip.ptr(a), n, float(rcond), _hip.ptr(out)))
+    return out
 
 
 def _model_kind(enm):

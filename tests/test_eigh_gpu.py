@@ -265,3 +265,32 @@ def test_config5_anm_n8000_lowest_modes(sc):
     rel = np.abs(w[6:] - ref[6:]) / np.abs(ref[6:])
     assert rel.max() <= 1e-5, rel.max()
     assert np.abs(v @ v.T - np.eye(106)).max() <= 1e-8
+
+
+# ---- F1: covariance = Hermitian pseudo-inverse on device -----------------------------------------------------
+
+@pytest.mark.parametrize("name", ["1l2y", "7cal"])
+def test_covariance_moore_penrose(sc, name):
+    # reference test: tests/test_anm.py:26-37 (both PDBs; 7cal is 5328 x 5328)
+    ca = structures()[f"{name}_coord"]
+    anm = sc.ANM(ca, sc.InvariantForceField(13.0))
+    h, c = anm.hessian, anm.covariance
+    assert np.allclose(h, h @ (c @ h))
+    assert np.allclose(c, c @ (h @ c))
+    if name == "1l2y":
+        assert np.allclose(c, np.linalg.pinv(h, hermitian=True, rcond=1e-6), rtol=1e-8, atol=1e-10)
+        anm2 = sc.ANM(ca, sc.InvariantForceField(13.0))
+        anm2.covariance = c                                   # hessian is rebuilt by pinv (anm.py:114-117)
+        assert np.allclose(anm2.hessian, h, atol=1e-8)
+
+
+def test_pinvh_matches_numpy(sc):
+    rs = np.random.RandomState(3)
+    q, _ = np.linalg.qr(rs.randn(200, 200))
+    lam = np.concatenate([np.zeros(5), rs.rand(195) + 0.5])
+    a = (q * lam) @ q.T
+    a = 0.5 * (a + a.T)
+    assert np.allclose(sc.nma.pinvh(a), np.linalg.pinv(a, hermitian=True, rcond=1e-6), atol=1e-10)
+    gnm = sc.GNM(synthetic_coord(60, 2, 15.0), sc.InvariantForceField(7.0))
+    k = gnm.kirchhoff
+    assert np.allclose(gnm.covariance, np.linalg.pinv(k, hermitian=True, rcond=1e-6), atol=1e-10)
