@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtL
 }
 
 int w1_splits_for(int ncols, int batch) {
-  const int col_tiles = (ncols + 127) / 128;
-  int s = (768 + col_tiles * batch - 1) / (col_tiles * batch);
+  // W1 is only NBT rows tall: 2 x ceil(ncols/64) tiles of 64x64 per matrix; split K until ~3000 workgroups exist
+  const int tiles = 2 * ((ncols + 63) / 64) * batch;
+  const int s = (3000 + tiles - 1) / tiles;
   return std::max(1, std::min(8, s));
 }
 
@@ -177,16 +178,16 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
 
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
                      nref);
-  SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, 0, BL.splits_g));
+  SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g));
   hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)npanels, (unsigned)batch), dim3(256),
                      sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
-  SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, 0));
+  SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile));
 
   for (int p = npanels - 1; p >= 0; --p) {
     const int mrow = n - p * nbt - 1;
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, 0, w1s));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s));
     hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, 0));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile));
   }
   SC_HIP(ctx, hipGetLastError());
   SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload

@@ -4,13 +4,26 @@
 // Also owns the workspace layout: everything the stages need is carved out of ONE cached device
 // allocation per context (sc_ctx::ws), sized by eigh_workspace_bytes().
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "eigh_internal.h"
 
 namespace {
 
-constexpr int kNb = 64;  // tridiagonalisation panel width (SYR2K inner dimension = 2 * kNb)
+// Tridiagonalisation panel width nb (SYR2K inner dimension K = 2 nb).  Measured on MI355X, N = 2000 C-alpha,
+// 8 structures in flight (profiles/r01_panel_width.txt): nb = 64: SYR2K 27.5 TFLOP/s (35 % of the 78.6 TFLOP/s
+// f64-MFMA peak), 52.7k modes/s; nb = 96: 31.7 TFLOP/s (40 %), 51.9k; nb = 128: 34.1 TFLOP/s (43 %), 50.7k
+// (wider panels make the per-column kernels read more V / W).  Default 96; SPRINGCRAFT_NB = 32|64|96|128 overrides.
+int panel_width() {
+  static int nb = [] {
+    const char* e = getenv("SPRINGCRAFT_NB");
+    const int v = e ? atoi(e) : 96;
+    return (v == 128 || v == 96 || v == 64 || v == 32) ? v : 96;
+  }();
+  return nb;
+}
+#define kNb (panel_width())
 
 size_t tri_slab_doubles(int n, TriLayout* out) {
   TriLayout L{};
@@ -313,7 +326,7 @@ int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_
     D.c = d_out; D.ldc = n; D.m = n; D.n = n; D.k = n;
     D.alpha = 1.0; D.beta = 0.0;
     if (hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, st) != hipSuccess) rc = SC_ERR_HIP;
-    if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, 0);
+    if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile);
     if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;
   }
   (void)hipFree(d_w); (void)hipFree(d_q); (void)hipFree(d_qs); (void)hipFree(d_desc);

@@ -31,8 +31,14 @@ struct GemmDesc {
   long long split_stride; // split-K launches: slice s writes alpha*partial to C + s*split_stride (beta ignored)
 };
 
+// Default block tile of the solver's GEMMs: 64 x 64 x 8 (tile id 3).  On gfx950 the f64 MFMA is slow enough
+// (64+ cycles per 16x16x4) that operand traffic is never the limit; what pays is occupancy — 3-5 resident
+// workgroups per CU whose load / MFMA / store phases overlap.  Measured (profiles/r01_gemm_shapes.txt):
+// 6000^3 43 TFLOP/s vs 33 with 128x128x16 tiles; SYR2K K=128 27 vs 18; K=256 32 vs 22.
+constexpr int kGemmTile = 3;
+
 // Launch `count` problems (records d_desc[0..count)); max_m / max_n bound the grid.
-// tile: 0 = 128x128 block tile, 1 = 64x128 (short-and-wide products).
+// tile: 0 = 128x128x16 block tile, 1 = 64x128x16, 2 = 64x64x16, 3 = 64x64x8 (see kGemmTile).
 // split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
                     int split_k = 1);

@@ -21,12 +21,10 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-constexpr int BN = 128;
 constexpr int PAD = 16;
 
-template <int BM>
-__global__ __launch_bounds__(256, 2) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
+template <int BM, int BN, int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
@@ -230,14 +228,19 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
                     int split_k) {
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
-  const int bm = tile == 1 ? 64 : 128;
-  dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + BN - 1) / BN),
-            (unsigned)(count * split_k));
-  const size_t lds = sizeof(double) * 2 * BK * ((size_t)(bm + PAD) + (BN + PAD));
+  const int bm = tile == 0 ? 128 : 64;
+  const int bn = (tile == 2 || tile == 3) ? 64 : 128;
+  const int bk = tile == 3 ? 8 : 16;
+  dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(count * split_k));
+  const size_t lds = sizeof(double) * 2 * bk * ((size_t)(bm + PAD) + (bn + PAD));
   if (tile == 1)
-    hipLaunchKernelGGL(k_gemm_f64<64>, grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+    hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  else if (tile == 2)
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  else if (tile == 3)
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   else
-    hipLaunchKernelGGL(k_gemm_f64<128>, grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+    hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
 }

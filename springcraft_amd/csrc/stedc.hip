@@ -741,7 +741,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                        dim3(256), 0, st, d_dc_ws, DL, dn, w_new);
     hipLaunchKernelGGL(k_dc_copy_deflated, dim3((unsigned)maxN, (unsigned)G, (unsigned)batch), dim3(256), 0, st,
                        d_dc_ws, DL, dn, q_old, q_new, stride_q);
-    SC_TRY(launch_gemm_f64(ctx, descs, G * batch, maxN, maxN, 0));
+    SC_TRY(launch_gemm_f64(ctx, descs, G * batch, maxN, maxN, kGemmTile));
   }
   const long long w_final = (nlev % 2 == 0) ? DL.w0 : DL.w1;
   hipLaunchKernelGGL(k_dc_unscale, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st,

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_col_update(double* __restrict__ a_all,
                                                      double* __restrict__ ws_all, TriLayout L, int c,
                                                      int j0) {
   constexpr int NG = 16;
-  __shared__ double rowV[64], rowW[64], part[NG][64], sh[16], arow[64];
+  __shared__ double rowV[128], rowW[128], part[NG][64], sh[16], arow[64];
   const int n = L.n, nb = L.nb, i = c - j0;
   const int nba = (n + 63) >> 6;
   double* A = a_all + (size_t)blockIdx.y * stride_a;
@@ -108,11 +108,12 @@ __global__ __launch_bounds__(1024) void k_col_update(double* __restrict__ a_all,
   }
   __syncthreads();
 
-  // each group owns reflectors p = g, g+16, g+32, g+48 (nb <= 64): keep their V / W entries for the dots below
-  double vk[4], wk[4];
+  // each group owns reflectors p = g, g+16, ..., g+112 (nb <= 128): keep their V / W entries for the dots below
+  constexpr int NU = 8;
+  double vk[NU], wk[NU];
   double acc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int p = g + NG * u;
     vk[u] = 0.0;
     wk[u] = 0.0;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_col_update(double* __restrict__ a_all,
   const double ar = arow[lane];
   const int blk = (c >> 6) + blockIdx.x;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int p = g + NG * u;
     if (p < i) {  // wave-uniform
       const double sv = wave_sum(vk[u] * ar);
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_w_reduce(double* __restrict__ a_all, l
                                                    double* __restrict__ ws_all, TriLayout L, int c,
                                                    int j0) {
   constexpr int NG = 16;
-  __shared__ double dots[8][128], part[NG][64];
+  __shared__ double dots[4][256], part[NG][64];
   const int n = L.n, nb = L.nb, i = c - j0;
   const int nba = (n + 63) >> 6, b0 = first_block(c + 1);
   const double* A = a_all + (size_t)blockIdx.y * stride_a;
@@ -349,19 +350,17 @@ __global__ __launch_bounds__(1024) void k_w_reduce(double* __restrict__ a_all, l
   double* WV = ws + L.wv;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   {
-    const int col = tid & 127, part8 = tid >> 7;   // 8 slices of the block range per dot column
+    const int col = tid & 255, slice = tid >> 8;   // 4 slices of the block range per dot column (2 nb <= 256)
     const int p = col < nb ? col : col - nb;
     double s = 0.0;
-    if (p < i)
-      for (int b = first_block(c) + part8; b < nba; b += 8) s += ws[L.dpart + (size_t)b * 2 * nb + col];
-    dots[part8][col] = s;  // partial sums over rows >= c+2 of V[r,p] a[r] / W[r,p] a[r] (k_col_update)
+    if (col < 2 * nb && p < i)
+      for (int b = first_block(c) + slice; b < nba; b += 4) s += ws[L.dpart + (size_t)b * 2 * nb + col];
+    dots[slice][col] = s;  // partial sums over rows >= c+2 of V[r,p] a[r] / W[r,p] a[r] (k_col_update)
   }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < 2 * nb) {
     const int p = tid < nb ? tid : tid - nb;
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += dots[q][tid];
+    const double s = (dots[0][tid] + dots[1][tid]) + (dots[2][tid] + dots[3][tid]);
     // v = (1, scale * a[c+2:]):  [p] = V_p^T v, [nb+p] = W_p^T v
     dots[0][tid] = p < i ? ws[L.hscale] * s + VW[(size_t)tid * n + c + 1] : 0.0;
   }
@@ -506,7 +505,7 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
       }
       const int mt = n - pend;
       if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-      SC_TRY(launch_gemm_f64(ctx, d_syr2k_descs + (size_t)panel * batch, batch, mt, mt, 0));
+      SC_TRY(launch_gemm_f64(ctx, d_syr2k_descs + (size_t)panel * batch, batch, mt, mt, kGemmTile));
       if (prof) {
         SC_HIP(ctx, hipEventRecord(ev[3], st));
         SC_HIP(ctx, hipEventSynchronize(ev[3]));

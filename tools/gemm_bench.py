@@ -17,8 +17,25 @@ cases = [
     ("merge NN 3000^3", 3000, 3000, 3000, 0, 0, 1, 0),
     ("syr2k NT lower K=128", 6000, 6000, 128, 1, 0, 1, 1),
     ("syr2k NT lower K=256", 6000, 6000, 256, 1, 0, 1, 1),
-    ("syr2k NT lower K=128 t1", 6000, 6000, 128, 1, 1, 1, 1),
-    ("bt update NN K=128 t1", 6000, 6000, 128, 0, 1, 1, 1),
+    ("syr2k NT lower K=128 t2", 6000, 6000, 128, 1, 2, 1, 1),
+    ("syr2k NT lower K=256 t2", 6000, 6000, 256, 1, 2, 1, 1),
+    ("bt update NN K=128 t2", 6000, 6000, 128, 0, 2, 1, 1),
+    ("bt update NN K=256 t2", 6000, 6000, 256, 0, 2, 1, 1),
+    ("merge NN 3000^3 t2", 3000, 3000, 3000, 0, 2, 1, 0),
+    ("merge NN 6000^3 t2", 6000, 6000, 6000, 0, 2, 1, 0),
+    ("syr2k NT lower K=128 t3", 6000, 6000, 128, 1, 3, 1, 1),
+    ("syr2k NT lower K=256 t3", 6000, 6000, 256, 1, 3, 1, 1),
+    ("bt update NN K=128 t3", 6000, 6000, 128, 0, 3, 1, 1),
+    ("merge NN 3000^3 t3", 3000, 3000, 3000, 0, 3, 1, 0),
+    ("merge NN 6000^3 t3", 6000, 6000, 6000, 0, 3, 1, 0),
+    ("bt W1 TN m=128 split8 t3", 128, 6000, 6000, 2, 3, 8, 0),
+    ("bt W1 TN m=128 split4 t3", 128, 6000, 6000, 2, 3, 4, 0),
+    ("bt W1 TN m=128 split2 t3", 128, 6000, 6000, 2, 3, 2, 0),
+    ("bt update NN K=256 t3", 6000, 6000, 256, 0, 3, 1, 1),
+    ("vt NN 6000x128x128 t3", 6000, 128, 128, 0, 3, 1, 0),
+    ("square NN 1536 t3", 1536, 1536, 1536, 0, 3, 1, 0),
+    ("bt W1 TN m=128 split8 t2", 128, 6000, 6000, 2, 2, 8, 0),
+    ("bt W1 TN m=128 split4 t2", 128, 6000, 6000, 2, 2, 4, 0),
     ("bt update NN K=64", 6000, 6000, 64, 0, 0, 1, 1),
     ("bt update NN K=128", 6000, 6000, 128, 0, 0, 1, 1),
     ("bt update NN K=256", 6000, 6000, 256, 0, 0, 1, 1),
