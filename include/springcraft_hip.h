@@ -47,19 +47,39 @@ extern "C" {
  *   SC_FF_HINSEN          d = max(sqrt(d2), 2.9); d < 4 ? 860 d - 2390 : 1.28e6 d^-6
  *                                                          (forcefield.py:292-330)
  *   SC_FF_PARAMETER_FREE  gamma = 1 / d2                  (forcefield.py:333-366)
- * Anything else (TabulatedForceField, user subclasses) goes through the *_from_pairs entry
- * points: the library returns the ordered pair list + squared distances, the host evaluates
+ * TabulatedForceField has its own descriptor (SC_FF_TABULATED below).  Anything else (user subclasses,
+ * nested patches) goes through the *_from_pairs entry points: the library returns the ordered pair list + squared distances, the host evaluates
  * force_constant() and hands gamma[k] back.
  */
 #define SC_FF_INVARIANT 0
 #define SC_FF_HINSEN 1
 #define SC_FF_PARAMETER_FREE 2
+#define SC_FF_TABULATED 3
+
+/* SC_FF_TABULATED: device-side restatement of TabulatedForceField (forcefield.py:369-533).  gamma(i,j,d2) is
+ * looked up in one of three float32 tables [type_i][type_j][bin] (C order (20,20,n_bins), the reference keeps
+ * them in float32, forcefield.py:889-891):  `bonded` when the two atoms are consecutive C-alpha of one chain
+ * (bonded_next[min(i,j)] and |i-j| == 1, forcefield.py:470-473,504-506), else `intra_chain` when
+ * chain[i] == chain[j], else `inter_chain`; bin = number of squared edges < d2
+ * (np.searchsorted(edges**2, d2), forcefield.py:521).  All pointers are HOST pointers. */
+typedef struct sc_tab_desc {
+  int32_t n_bins;             /* >= 1 */
+  int32_t reserved;
+  const double* edges_sq;     /* (n_bins,) squared right bin edges; may be NULL when n_bins == 1 */
+  const float* bonded;        /* (20,20,n_bins) */
+  const float* intra_chain;   /* (20,20,n_bins) */
+  const float* inter_chain;   /* (20,20,n_bins) */
+  const int32_t* atom_type;   /* (n_atoms,) amino-acid index 0..19 (alphabetical by one-letter code) */
+  const int32_t* chain;       /* (n_atoms,) integer chain label */
+  const uint8_t* bonded_next; /* (n_atoms,) 1: atom i is peptide-bonded to atom i+1 */
+} sc_tab_desc;
 
 typedef struct sc_ff_desc {
   int32_t kind;       /* SC_FF_* */
   int32_t has_cutoff; /* 0: cutoff_distance is None -> every i != j is a contact (interaction.py:151-153) */
   double cutoff;      /* cutoff_distance in Angstrom (informational) */
   double cutoff_sq;   /* cutoff_distance**2 evaluated by the host in float64 (interaction.py:166) */
+  const sc_tab_desc* tab; /* SC_FF_TABULATED only, else NULL */
 } sc_ff_desc;
 
 /* ---- contact patches (ForceField.contact_shutdown / contact_pair_off / contact_pair_on,

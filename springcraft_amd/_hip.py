@@ -29,6 +29,7 @@ SC_ERR_NOCONV = 7
 SC_FF_INVARIANT = 0
 SC_FF_HINSEN = 1
 SC_FF_PARAMETER_FREE = 2
+SC_FF_TABULATED = 3
 
 # every symbol include/springcraft_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
@@ -45,12 +46,27 @@ class HipUnavailableError(RuntimeError):
     """The HIP extension (or an MI355X device) is not available; there is no fallback."""
 
 
+class TabDesc(C.Structure):
+    _fields_ = [
+        ("n_bins", C.c_int32),
+        ("reserved", C.c_int32),
+        ("edges_sq", C.c_void_p),
+        ("bonded", C.c_void_p),
+        ("intra_chain", C.c_void_p),
+        ("inter_chain", C.c_void_p),
+        ("atom_type", C.c_void_p),
+        ("chain", C.c_void_p),
+        ("bonded_next", C.c_void_p),
+    ]
+
+
 class FFDesc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
         ("has_cutoff", C.c_int32),
         ("cutoff", C.c_double),
         ("cutoff_sq", C.c_double),
+        ("tab", C.POINTER(TabDesc)),
     ]
 
 
@@ -223,6 +239,31 @@ def make_ff_desc(kind, cutoff_distance):
         # interaction.py:166 squares the cutoff in Python / NumPy float64 arithmetic
         d.cutoff_sq = float(np.float64(cutoff_distance) ** 2)
     return d
+
+
+def make_tab_desc(ff_desc, edges, bonded, intra, inter, atom_type, chain, bonded_next):
+    """
+    Attach the tables of a TabulatedForceField to ``ff_desc`` (kind SC_FF_TABULATED).  The arrays are kept
+    alive on the descriptor object itself (``ff_desc._keep``).
+    """
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    keep = [f32(bonded), f32(intra), f32(inter),
+            np.ascontiguousarray(atom_type, dtype=np.int32),
+            np.ascontiguousarray(chain, dtype=np.int32),
+            np.ascontiguousarray(bonded_next, dtype=np.uint8)]
+    t = TabDesc()
+    t.n_bins = keep[0].shape[-1]
+    if edges is not None:
+        e2 = np.ascontiguousarray(np.asarray(edges, dtype=np.float64) ** 2)   # forcefield.py:521 squares the edges
+        keep.append(e2)
+        t.edges_sq = e2.ctypes.data
+    t.bonded, t.intra_chain, t.inter_chain = (k.ctypes.data for k in keep[:3])
+    t.atom_type, t.chain, t.bonded_next = (k.ctypes.data for k in keep[3:6])
+    keep.append(t)
+    ff_desc.kind = SC_FF_TABULATED
+    ff_desc.tab = C.pointer(t)
+    ff_desc._keep = keep
+    return ff_desc
 
 
 def make_patch_desc(shutdown, pair_off, pair_on, on_force_constants, mask_gamma, keep):

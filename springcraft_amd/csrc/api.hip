@@ -75,8 +75,14 @@ int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
 
 int check_ff(sc_ctx* ctx, const sc_ff_desc* ff) {
   if (!ff) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "force-field descriptor is NULL");
-  if (ff->kind < SC_FF_INVARIANT || ff->kind > SC_FF_PARAMETER_FREE)
+  if (ff->kind < SC_FF_INVARIANT || ff->kind > SC_FF_TABULATED)
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "unknown force-field kind %d", ff->kind);
+  if (ff->kind == SC_FF_TABULATED) {
+    const sc_tab_desc* t = ff->tab;
+    if (!t || t->n_bins < 1 || !t->bonded || !t->intra_chain || !t->inter_chain || !t->atom_type || !t->chain ||
+        !t->bonded_next || (t->n_bins > 1 && !t->edges_sq))
+      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "incomplete tabulated force-field descriptor");
+  }
   if (ff->kind == SC_FF_INVARIANT && !ff->has_cutoff)
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "Cutoff distance must be a float");  // forcefield.py:277-281
   return SC_OK;
@@ -207,12 +213,58 @@ struct Staged {
   PatchDev patch{};
   bool has_patch = false;
   HostPatch hp;  // keeps host vectors alive until the stream is synchronised
+  sc_tab_desc tab_dev{};   // SC_FF_TABULATED: same fields, DEVICE pointers
+  sc_ff_desc ff_dev{};     // copy of the caller's descriptor with .tab -> &tab_dev
 };
 
-int stage_inputs(sc_ctx* ctx, const double* coord, int64_t n, const sc_patch_desc* pd,
+size_t tab_device_bytes(const sc_ff_desc* ff, int64_t n) {
+  if (!ff || ff->kind != SC_FF_TABULATED || !ff->tab) return 0;
+  const size_t nb = (size_t)ff->tab->n_bins;
+  return align_up(nb * 8, 256) + align_up(3 * 400 * nb * 4, 256) + 2 * align_up((size_t)n * 4, 256) +
+         align_up((size_t)n, 256) + 2048;
+}
+
+// Upload the tabulated force-field tables; st.ff_dev is what the kernel launchers must be given.
+int stage_tab(sc_ctx* ctx, const sc_ff_desc* ff, int64_t n, Staged& st, Bump& bump) {
+  st.ff_dev = *ff;
+  if (ff->kind != SC_FF_TABULATED) return SC_OK;
+  const sc_tab_desc* t = ff->tab;
+  const size_t nb = (size_t)t->n_bins;
+  for (int64_t i = 0; i < n; ++i)
+    if (t->atom_type[i] < 0 || t->atom_type[i] >= 20)
+      return sc_set_error(ctx, SC_ERR_INDEX, "amino-acid type %d of atom %lld out of range", t->atom_type[i],
+                          (long long)i);
+  double* d_edges = bump.take<double>(nb);
+  float* d_tab = bump.take<float>(3 * 400 * nb);
+  int32_t* d_type = bump.take<int32_t>((size_t)n);
+  int32_t* d_chain = bump.take<int32_t>((size_t)n);
+  uint8_t* d_bond = bump.take<uint8_t>((size_t)n);
+  hipStream_t s = ctx->stream;
+  if (t->edges_sq) SC_HIP(ctx, hipMemcpyAsync(d_edges, t->edges_sq, nb * 8, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_tab, t->bonded, 400 * nb * 4, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_tab + 400 * nb, t->intra_chain, 400 * nb * 4, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_tab + 800 * nb, t->inter_chain, 400 * nb * 4, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_type, t->atom_type, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_chain, t->chain, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipMemcpyAsync(d_bond, t->bonded_next, (size_t)n, hipMemcpyHostToDevice, s));
+  SC_HIP(ctx, hipStreamSynchronize(s));
+  st.tab_dev = *t;
+  st.tab_dev.edges_sq = d_edges;
+  st.tab_dev.bonded = d_tab;
+  st.tab_dev.intra_chain = d_tab + 400 * nb;
+  st.tab_dev.inter_chain = d_tab + 800 * nb;
+  st.tab_dev.atom_type = d_type;
+  st.tab_dev.chain = d_chain;
+  st.tab_dev.bonded_next = d_bond;
+  st.ff_dev.tab = &st.tab_dev;
+  return SC_OK;
+}
+
+int stage_inputs(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff, const sc_patch_desc* pd,
                  const double* inv_sqrt_mass, size_t extra_bytes, Staged& st, Bump& bump) {
   SC_TRY(build_patch(ctx, pd, n, st.hp));
-  size_t need = align_up((size_t)n * 24, 256) + align_up((size_t)n * 8, 256) + 1024 + extra_bytes;
+  size_t need = align_up((size_t)n * 24, 256) + align_up((size_t)n * 8, 256) + 1024 + extra_bytes +
+                tab_device_bytes(ff, n);
   if (st.hp.any) need += st.hp.device_bytes();
   SC_TRY(sc_reserve_scratch(ctx, need));
   bump.base = (char*)ctx->scratch;
@@ -227,6 +279,7 @@ int stage_inputs(sc_ctx* ctx, const double* coord, int64_t n, const sc_patch_des
     SC_TRY(upload_patch(ctx, st.hp, bump, st.patch));
     st.has_patch = true;
   }
+  SC_TRY(stage_tab(ctx, ff, n, st, bump));
   return SC_OK;
 }
 
@@ -288,9 +341,9 @@ int sc_contacts(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* f
   if (n == 0) return SC_OK;
   Staged st;
   Bump bump{};
-  SC_TRY(stage_inputs(ctx, coord, n, patch, nullptr, (size_t)n * 8 + 256, st, bump));
+  SC_TRY(stage_inputs(ctx, coord, n, ff, patch, nullptr, (size_t)n * 8 + 256, st, bump));
   int64_t* d_counts = bump.take<int64_t>((size_t)n);
-  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, *ff, st.has_patch ? &st.patch : nullptr, d_counts));
+  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, st.ff_dev, st.has_patch ? &st.patch : nullptr, d_counts));
   std::vector<int64_t> h((size_t)n);
   SC_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -314,13 +367,13 @@ int sc_pairs(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
   Staged st;
   Bump bump{};
   const size_t extra = (size_t)(2 * n + 2) * 8 + (size_t)capacity * 24 + 2048;
-  SC_TRY(stage_inputs(ctx, coord, n, patch, nullptr, extra, st, bump));
+  SC_TRY(stage_inputs(ctx, coord, n, ff, patch, nullptr, extra, st, bump));
   int64_t* d_counts = bump.take<int64_t>((size_t)n);
   int64_t* d_off = bump.take<int64_t>((size_t)n + 1);
   int64_t* d_pairs = bump.take<int64_t>((size_t)capacity * 2 + 2);
   double* d_sq = sq_dist ? bump.take<double>((size_t)capacity + 1) : nullptr;
   const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
-  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, *ff, pdev, d_counts));
+  SC_TRY(launch_contact_counts(ctx, st.d_coord, n, st.ff_dev, pdev, d_counts));
   std::vector<int64_t> h((size_t)n + 1);
   SC_HIP(ctx, hipMemcpyAsync(h.data() + 1, d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -333,7 +386,7 @@ int sc_pairs(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
                         (long long)capacity);
   if (k == 0) return SC_OK;
   SC_HIP(ctx, hipMemcpyAsync(d_off, h.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  SC_TRY(launch_pair_fill(ctx, st.d_coord, n, *ff, pdev, d_off, d_pairs, d_sq));
+  SC_TRY(launch_pair_fill(ctx, st.d_coord, n, st.ff_dev, pdev, d_off, d_pairs, d_sq));
   SC_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, (size_t)k * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (sq_dist)
     SC_HIP(ctx, hipMemcpyAsync(sq_dist, d_sq, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -352,13 +405,13 @@ static int assemble_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_f
   const size_t elems = (size_t)n * n * dim * dim;
   Staged st;
   Bump bump{};
-  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass, elems * 8 + 512, st, bump));
+  SC_TRY(stage_inputs(ctx, coord, n, ff, patch, inv_sqrt_mass, elems * 8 + 512, st, bump));
   double* d_m = bump.take<double>(elems);
   const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
   if (dim == 1)
-    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m, nullptr));
+    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m, nullptr));
   else
-    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m));
+    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m));
   SC_HIP(ctx, hipMemcpyAsync(out, d_m, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
@@ -501,12 +554,12 @@ int sc_anm_eigen_range_f64(sc_ctx* ctx, const double* coord, int64_t n, const sc
   const size_t elems = (size_t)dim3n * dim3n;
   Staged st;
   Bump bump{};
-  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass,
+  SC_TRY(stage_inputs(ctx, coord, n, ff, patch, inv_sqrt_mass,
                       elems * 8 + (size_t)m * 8 + (v ? (size_t)m * dim3n * 8 : 0) + 4096, st, bump));
   double* d_m = bump.take<double>(elems);
   double* d_w = bump.take<double>((size_t)m);
   double* d_v = v ? bump.take<double>((size_t)m * dim3n) : nullptr;
-  SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, st.has_patch ? &st.patch : nullptr, st.d_w, d_m));
+  SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, st.ff_dev, st.has_patch ? &st.patch : nullptr, st.d_w, d_m));
   SC_TRY(eigh_range_batched(ctx, d_m, dim3n, 1, il, iu, d_w, d_v));
   SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, (size_t)m * dim3n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -534,16 +587,16 @@ static int enm_eigen_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_
   const size_t elems = (size_t)m * m;
   Staged st;
   Bump bump{};
-  SC_TRY(stage_inputs(ctx, coord, n, patch, inv_sqrt_mass,
+  SC_TRY(stage_inputs(ctx, coord, n, ff, patch, inv_sqrt_mass,
                       elems * 8 * (v ? 2 : 1) + (size_t)m * 8 + 2048, st, bump));
   double* d_m = bump.take<double>(elems);
   double* d_w = bump.take<double>((size_t)m);
   double* d_v = v ? bump.take<double>(elems) : nullptr;
   const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
   if (dim == 1)
-    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m, nullptr));
+    SC_TRY(launch_kirchhoff(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m, nullptr));
   else
-    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, *ff, pdev, st.d_w, d_m));
+    SC_TRY(launch_hessian(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m));
   SC_TRY(eigh_batched(ctx, d_m, m, 1, d_w, d_v));
   SC_HIP(ctx, hipMemcpyAsync(w, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (v) SC_HIP(ctx, hipMemcpyAsync(v, d_v, elems * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -565,6 +618,8 @@ int sc_dev_kirchhoff_f64(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t 
                          const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix) {
   if (!ctx) return SC_ERR_INVALID_ARG;
   SC_TRY(check_ff(ctx, ff));
+  if (ff->kind == SC_FF_TABULATED)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "tabulated force fields are not supported on the batched device path");
   if (n < 0 || batch < 0 || (n > 0 && batch > 0 && (!d_coord || !d_matrix)))
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
   SC_HIP(ctx, hipSetDevice(ctx->device));
@@ -575,6 +630,8 @@ int sc_dev_hessian_f64(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t ba
                        const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix) {
   if (!ctx) return SC_ERR_INVALID_ARG;
   SC_TRY(check_ff(ctx, ff));
+  if (ff->kind == SC_FF_TABULATED)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "tabulated force fields are not supported on the batched device path");
   if (n < 0 || batch < 0 || (n > 0 && batch > 0 && (!d_coord || !d_matrix)))
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
   SC_HIP(ctx, hipSetDevice(ctx->device));

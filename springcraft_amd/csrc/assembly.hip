@@ -17,9 +17,35 @@ struct FFDev {
   int kind;
   int has_cutoff;
   double cutoff_sq;
+  // SC_FF_TABULATED (device pointers)
+  int n_bins;
+  const double* edges_sq;
+  const float* tab;            // [3][20][20][n_bins]: bonded, intra-chain, inter-chain
+  const int* atom_type;
+  const int* chain;
+  const unsigned char* bonded_next;
 };
 
-__device__ __forceinline__ double ff_gamma(int kind, double d2) {
+// TabulatedForceField.force_constant (forcefield.py:515-533) from the type tables
+__device__ __forceinline__ double tab_gamma(const FFDev& ff, int i, int j, double d2) {
+  int bin = 0;
+  if (ff.n_bins > 1) {
+    int lo = 0, hi = ff.n_bins;   // np.searchsorted(edges**2, d2, side='left'): number of edges^2 < d2
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ff.edges_sq[mid] < d2) lo = mid + 1; else hi = mid;
+    }
+    bin = lo < ff.n_bins ? lo : ff.n_bins - 1;
+  }
+  const int a = i < j ? i : j, b = i < j ? j : i;
+  int which;
+  if (b == a + 1 && ff.bonded_next[a]) which = 0;
+  else which = (ff.chain[i] == ff.chain[j]) ? 1 : 2;
+  const int ti = ff.atom_type[i], tj = ff.atom_type[j];
+  return (double)ff.tab[((size_t)(which * 20 + ti) * 20 + tj) * ff.n_bins + bin];
+}
+
+__device__ __forceinline__ double ff_gamma_dist(int kind, double d2) {
   if (kind == SC_FF_INVARIANT) return 1.0;               // forcefield.py:284-285
   if (kind == SC_FF_PARAMETER_FREE) return 1.0 / d2;     // forcefield.py:361-362
   // Hinsen, forcefield.py:321-326
@@ -55,11 +81,12 @@ __device__ __forceinline__ bool pair_eval(int i, int j, double cix, double ciy, 
     }
     if (contact) {
       // PatchedForceField.force_constant, forcefield.py:183-226
-      gamma = (patch.mask_gamma && !within) ? 0.0 : ff_gamma(ff.kind, d2);
+      gamma = (patch.mask_gamma && !within) ? 0.0
+              : (ff.kind == SC_FF_TABULATED ? tab_gamma(ff, i, j, d2) : ff_gamma_dist(ff.kind, d2));
       if (gover == gover) gamma = gover;
     }
   } else {
-    if (contact) gamma = ff_gamma(ff.kind, d2);
+    if (contact) gamma = ff.kind == SC_FF_TABULATED ? tab_gamma(ff, i, j, d2) : ff_gamma_dist(ff.kind, d2);
   }
   return contact;
 }
@@ -363,7 +390,22 @@ __global__ void k_hessian_diag(int n, double* __restrict__ H) {
   H[(3 * i + a) * n3 + c] = -s;
 }
 
-FFDev make_ff(const sc_ff_desc& ff) { return FFDev{ff.kind, ff.has_cutoff, ff.cutoff_sq}; }
+// ff.tab, when set, has already been replaced by a descriptor holding DEVICE pointers (api.hip:stage_tab)
+FFDev make_ff(const sc_ff_desc& ff) {
+  FFDev d{};
+  d.kind = ff.kind;
+  d.has_cutoff = ff.has_cutoff;
+  d.cutoff_sq = ff.cutoff_sq;
+  if (ff.kind == SC_FF_TABULATED && ff.tab) {
+    d.n_bins = ff.tab->n_bins;
+    d.edges_sq = ff.tab->edges_sq;
+    d.tab = ff.tab->bonded;   // the three tables are uploaded back to back
+    d.atom_type = ff.tab->atom_type;
+    d.chain = ff.tab->chain;
+    d.bonded_next = ff.tab->bonded_next;
+  }
+  return d;
+}
 
 }  // namespace
 

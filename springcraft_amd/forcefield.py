@@ -250,10 +250,18 @@ def device_plan(force_field):
     ``patch_args`` = (shutdown, pair_off, pair_on, on_force_constants, mask_gamma).
     """
     cutoff = force_field.cutoff_distance
-    if _exact_builtin(force_field):
-        return _hip.make_ff_desc(force_field._device_kind(), cutoff), None, True
-    if type(force_field) is PatchedForceField and _exact_builtin(force_field._force_field):
-        base = force_field._force_field
+
+    def fusable(ff):
+        return _exact_builtin(ff) or (type(ff) is TabulatedForceField and not ff._matrix_exposed)
+
+    def base_desc(ff):
+        if type(ff) is TabulatedForceField:
+            return ff._tab_desc(_hip.make_ff_desc(_hip.SC_FF_TABULATED, cutoff))
+        return _hip.make_ff_desc(ff._device_kind(), cutoff)
+
+    if fusable(force_field):
+        return base_desc(force_field), None, True
+    if type(force_field) is PatchedForceField and fusable(force_field._force_field):
         patch = (
             force_field._contact_shutdown,
             force_field._contact_pair_off,
@@ -261,7 +269,7 @@ def device_plan(force_field):
             force_field._force_constants,
             True,
         )
-        return _hip.make_ff_desc(base._device_kind(), cutoff), patch, True
+        return base_desc(force_field._force_field), patch, True
     # callback path: the scan only needs the cutoff and the adjacency patches
     patch = (
         force_field.contact_shutdown,
@@ -326,6 +334,13 @@ class TabulatedForceField(ForceField):
         idx = np.arange(n)
         matrix[idx, idx, :] = 0
         self._interaction_matrix = matrix
+        # device descriptor inputs (the tables reproduce the matrix above); handing out the matrix for in-place
+        # edits (interaction_matrix property) switches this object to the host-callback path
+        _, chain_codes = np.unique(chain, return_inverse=True)
+        bonded_next = np.zeros(n, dtype=np.uint8)
+        bonded_next[bond] = 1
+        self._device_tables = (types.astype(np.int32), chain_codes.astype(np.int32), bonded_next)
+        self._matrix_exposed = False
 
     def force_constant(self, atom_i, atom_j, sq_distance):
         if self._edges is None or len(self._edges) == 1:
@@ -347,7 +362,14 @@ class TabulatedForceField(ForceField):
 
     @property
     def interaction_matrix(self):
+        self._matrix_exposed = True
         return self._interaction_matrix
+
+    def _tab_desc(self, ff_desc):
+        types, chain_codes, bonded_next = self._device_tables
+        return _hip.make_tab_desc(ff_desc, self._edges if (self._edges is not None and len(self._edges) > 1) else None,
+                                  self._bonded, self._intra_chain, self._inter_chain, types, chain_codes,
+                                  bonded_next)
 
     # ---- literature parameter sets (reference: forcefield.py:547-876) -----------------------
     # The published tables ship as CSV data next to this module (springcraft_amd/data).
@@ -432,10 +454,13 @@ def _check_symmetric(table):
         raise ValueError("Input matrix is not symmetric")
 
 
-_tables = {}
+_tables = None
 
 
 def _load_table(fname):
-    if fname not in _tables:
-        _tables[fname] = np.loadtxt(join(DATA_DIR, fname), delimiter=",")
-    return _tables[fname]
+    """Published parameter tables, packed by tools/make_tables.py into data/enm_tables.npz."""
+    global _tables
+    if _tables is None:
+        with np.load(join(DATA_DIR, "enm_tables.npz")) as z:
+            _tables = {k: z[k] for k in z.files}
+    return _tables[fname.replace(".csv", "")]
