@@ -214,6 +214,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 spends ~12 s in the CPU baseline; leave together
         dist.destroy_process_group()
 
 
