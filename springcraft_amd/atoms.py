@@ -85,9 +85,11 @@ def read_pdb_ca(path, model=1):
         for line in f:
             rec = line[:6]
             if rec == "MODEL ":
-                current = int(line[10:14])
-            elif rec == "ENDMDL" and current == model:
-                break
+                current = int(line[6:].split()[0])
+            elif rec == "ENDMDL":
+                if current == model:
+                    break
+                current += 1          # files without explicit MODEL numbering
             elif rec == "ATOM  " and current == model:
                 if line[12:16].strip() != "CA" or line[76:78].strip() != "C":
                     continue
