@@ -188,7 +188,6 @@ def test_pdb_adaptor_and_residue_masses():
     assert np.array_equal(ca.coord, s["1l2y_coord"]) and ca.coord.dtype == np.float32
     assert list(ca.res_name) == list(s["1l2y_res_name"])
     assert list(ca.res_id) == list(s["1l2y_res_id"])
-    assert sc.read_pdb_ca(ref_data("1l2y.pdb"), model=2).array_length() == 20     # NMR ensemble: other models too
     anm = sc.ANM(ca, sc.InvariantForceField(13.0), masses=True)
     # masses=True uses the free amino-acid masses (what biotite's info.mass(res_name, is_residue=True) reports)
     assert anm.masses.shape == (20,)
