@@ -68,7 +68,7 @@ Plan make_plan(int n, int batch, bool vectors) {
     P.off_bt = take(bt_slab_doubles(n, &P.BL) * 8 * batch);
     P.off_qtmp = take((size_t)n * n * 8 * batch);
     P.off_u = take((size_t)n * n * 8 * batch);
-    P.n_merge = dc_max_nodes(n, P.DL.leaf_max) * batch;
+    P.n_merge = 2 * dc_max_nodes(n, P.DL.leaf_max) * batch;   // two half-GEMMs per merge
     P.n_bt = bt_desc_count(n, batch);
   }
   P.off_desc = take(sizeof(GemmDesc) * ((size_t)P.n_syr2k + P.n_merge + P.n_bt + 8));

@@ -49,6 +49,8 @@ struct DcLayout {
   long long org;     // int[n]: origin pole of each root
   long long dest;    // int[n]: destination column of non-deflated k (at lo+k) / deflated (at lo+K+e)
   long long rot_a, rot_b;  // int[n] each: rotated column pairs
+  long long ktop_src, ktop_k;  // int[n] each: columns that are non-zero in the node's TOP half: source column / pole index
+  long long kbot_src, kbot_k;  // same for the BOTTOM half
   long long cnt;     // int[2 * max_nodes]: per node K and number of rotations
 };
 
@@ -58,7 +60,7 @@ struct DcLayout {
 int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const TriLayout& TL,
                   double* d_dc_ws, const DcLayout& DL, double* d_w, long long stride_w,
                   double* d_q_out, double* d_q_tmp, double* d_u, long long stride_q,
-                  GemmDesc* d_merge_descs /* max_nodes_per_level * batch */);
+                  GemmDesc* d_merge_descs /* 2 * dc_max_nodes * batch */);
 size_t dc_slab_doubles(int n, DcLayout* out);
 int dc_max_nodes(int n, int leaf_max);
 

@@ -25,6 +25,7 @@ struct GemmDesc {
   long long ldc;          // column stride of C (row stride is 1)
   double alpha, beta;
   const int* a_kidx;      // optional gather on A's k axis: A(i,k) = a[i*sa_i + a_kidx[k]*sa_k]
+  const int* b_kidx;      // optional gather on B's k axis: B(k,j) = b[b_kidx[k]*sb_k + j*sb_j]
   const int* c_jidx;      // optional scatter on C's column axis: C(:, j) lives at column c_jidx[j]
   int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K)
   int row_off, col_off;
@@ -40,5 +41,6 @@ constexpr int kGemmTile = 3;
 // Launch `count` problems (records d_desc[0..count)); max_m / max_n bound the grid.
 // tile: 0 = 128x128x16 block tile, 1 = 64x128x16, 2 = 64x64x16, 3 = 64x64x8 (see kGemmTile).
 // split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
+// gather: the records carry a_kidx / b_kidx lists (D&C merges); uses the 64x64x8 tile whatever `tile` says.
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k = 1);
+                    int split_k = 1, bool gather = false);

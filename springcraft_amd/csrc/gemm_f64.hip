@@ -23,7 +23,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int PAD = 16;
 
-template <int BM, int BN, int BK, int MINW>
+template <int BM, int BN, int BK, int MINW, bool GATHER>
 __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
   const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
   const int M = D.m, N = D.n, K = D.k;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (m0 >= M || n0 >= N || K <= 0) return;
+  if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
   if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
 
   int k_begin = 0, k_end = K;
@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
   const double* __restrict__ A = D.a;
   const double* __restrict__ B = D.b;
   const long long sa_i = D.sa_i, sa_k = D.sa_k, sb_k = D.sb_k, sb_j = D.sb_j;
-  const int* __restrict__ kidx = D.a_kidx;
+  // gather lists are only looked at by the GATHER instantiation (the D&C merges); the plain one pays nothing
+  const int* __restrict__ kidx = GATHER ? D.a_kidx : nullptr;
+  const int* __restrict__ bkidx = GATHER ? D.b_kidx : nullptr;
   const bool a_mcontig = (sa_i == 1);
   const bool b_ncontig = (sb_j == 1);
 
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
         const int gi = m0 + i;
         double v = 0.0;
         if (gi < M && k < k_end) {
-          const long long kk = kidx ? (long long)kidx[k] : (long long)k;
+          const long long kk = (GATHER && kidx) ? (long long)kidx[k] : (long long)k;
           v = A[(long long)gi + kk * sa_k];
         }
         ra[p] = v;
@@ -96,7 +98,9 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
       for (int p = 0; p < B_PER_THREAD; ++p) {
         const int k = kt + kq + p * KSTEP;
         const int gj = n0 + j;
-        rb[p] = (gj < N && k < k_end) ? B[(long long)k * sb_k + gj] : 0.0;
+        double v = 0.0;
+        if (gj < N && k < k_end) v = B[((GATHER && bkidx) ? (long long)bkidx[k] : (long long)k) * sb_k + gj];
+        rb[p] = v;
       }
     } else {
       const int k = tid % BK, jq = tid / BK;
@@ -105,7 +109,10 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
       for (int p = 0; p < B_PER_THREAD; ++p) {
         const int gj = n0 + jq + p * JSTEP;
         const int gk = kt + k;
-        rb[p] = (gj < N && gk < k_end) ? B[(long long)gk + (long long)gj * sb_j] : 0.0;
+        double v = 0.0;
+        if (gj < N && gk < k_end)
+          v = B[((GATHER && bkidx) ? (long long)bkidx[gk] : (long long)gk) + (long long)gj * sb_j];
+        rb[p] = v;
       }
     }
   };
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
 }  // namespace
 
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k) {
+                    int split_k, bool gather) {
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
   const int bm = tile == 0 ? 128 : 64;
@@ -233,14 +240,16 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   const int bk = tile == 3 ? 8 : 16;
   dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(count * split_k));
   const size_t lds = sizeof(double) * 2 * bk * ((size_t)(bm + PAD) + (bn + PAD));
-  if (tile == 1)
-    hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  if (gather)   // only the default tile is instantiated with gather support
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, true>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  else if (tile == 1)
+    hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   else if (tile == 2)
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   else if (tile == 3)
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   else
-    hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+    hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
 }

@@ -16,7 +16,9 @@
 //   k_dc_vectors        eigenvectors of the rank-one problem, normalised (K x K matrix U)
 //   k_dc_finalize       merged ascending order: destinations of new + deflated columns, eigenvalues
 //   k_dc_copy_deflated  move deflated eigenvector columns
-//   MFMA GEMM           Q_new[:, dest] = Q_old[:, src] * U          (gemm_f64.hip, gather / scatter)
+//   MFMA GEMM x 2       Q_new[top rows, dest] = Q_old[top rows, src_top] * U[k_top, :]  and the same for the bottom
+//                       rows: blockdiag(Q1, Q2) is half zeros, each half-GEMM gathers only the columns that are
+//                       non-zero in its rows (gemm_f64.hip, gather on both operands' k axis, scatter on C's columns)
 #include <algorithm>
 #include <vector>
 
@@ -226,15 +228,18 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
   double* sd;
   double* sz;
   int* scol;
+  unsigned char* smix;   // 1: the column has been mixed across the two halves by a deflation rotation
   if (use_lds) {
     sd = lds;
     sz = lds + N;
     scol = reinterpret_cast<int*>(lds + 2 * N);
+    smix = reinterpret_cast<unsigned char*>(scol + N);
   } else {
     double* base = gscratch + (size_t)b * gscratch_stride + 3LL * lo;
     sd = base;
     sz = base + N;
     scol = reinterpret_cast<int*>(base + 2 * N);
+    smix = reinterpret_cast<unsigned char*>(scol + N);
   }
 
   const double rho_raw = ws[DL.ee + mid - 1];
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
     sd[rank] = v;
     sz[rank] = ws[DL.z + lo + j];
     scol[rank] = lo + j;
+    smix[rank] = 0;
   }
   __syncthreads();
 
@@ -292,7 +298,11 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
     int* rot_a = iptr(ws, DL.rot_a);
     int* rot_b = iptr(ws, DL.rot_b);
     int* cnt = iptr(ws, DL.cnt);
-    int K = 0, ndef = 0, nrot = 0;
+    int* ktop_src = iptr(ws, DL.ktop_src);
+    int* ktop_k = iptr(ws, DL.ktop_k);
+    int* kbot_src = iptr(ws, DL.kbot_src);
+    int* kbot_k = iptr(ws, DL.kbot_k);
+    int K = 0, ndef = 0, nrot = 0, K1 = 0, K3 = 0;
     auto deflate = [&](int jj) {
       ws[DL.ddef + hi - 1 - ndef] = sd[jj];
       src[hi - 1 - ndef] = scol[jj];
@@ -302,6 +312,11 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
       ws[DL.dl + lo + K] = sd[jj];
       ws[DL.zz + lo + K] = sz[jj];
       src[lo + K] = scol[jj];
+      // blockdiag(Q1, Q2): a column from the first child is zero in the bottom rows and vice versa, unless a
+      // deflation rotation mixed it (dlaed2's column types 1 / 2 / 3): the two half-GEMMs only take what is non-zero
+      const bool top = scol[jj] < mid;
+      if (top || smix[jj]) { ktop_src[lo + K1] = scol[jj]; ktop_k[lo + K1] = K; ++K1; }
+      if (!top || smix[jj]) { kbot_src[lo + K3] = scol[jj]; kbot_k[lo + K3] = K; ++K3; }
       ++K;
     };
     int pj = -1;
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
         ws[DL.rot_c + lo + nrot] = c;
         ws[DL.rot_s + lo + nrot] = s;
         ++nrot;
+        if (((scol[pj] < mid) != (scol[jj] < mid)) || smix[pj] || smix[jj]) { smix[jj] = 1; smix[pj] = 1; }
         const double tt = sd[pj] * c * c + sd[jj] * s * s;
         sd[jj] = sd[pj] * s * s + sd[jj] * c * c;
         sd[pj] = tt;
@@ -337,9 +353,12 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
     if (pj >= 0) accept(pj);
     cnt[2 * g] = K;
     cnt[2 * g + 1] = nrot;
-    GemmDesc& D = descs[(size_t)b * nodes_in_level + g];
-    D.n = K;
-    D.k = K;
+    GemmDesc& Dt = descs[((size_t)b * nodes_in_level + g) * 2];      // top rows
+    Dt.n = K;
+    Dt.k = K1;
+    GemmDesc& Db = descs[((size_t)b * nodes_in_level + g) * 2 + 1];  // bottom rows
+    Db.n = K;
+    Db.k = K3;
   }
 }
 
@@ -606,7 +625,7 @@ Tree build_tree(int n, int leaf_max) {
 }
 
 constexpr int kLeafMax = 32;
-constexpr int kLdsCapSetup = 7600;    // 20 B per element
+constexpr int kLdsCapSetup = 7300;    // 21 B per element
 constexpr int kLdsCapSecular = 9800;  // 16 B per pole
 
 }  // namespace
@@ -629,6 +648,7 @@ size_t dc_slab_doubles(int n, DcLayout* out) {
   L.dl = take(nn); L.zz = take(nn); L.ddef = take(nn); L.lam = take(nn); L.tauv = take(nn);
   L.zhat = take(nn); L.rot_c = take(nn); L.rot_s = take(nn); L.scale = take(8);
   L.src = take(nn); L.org = take(nn); L.dest = take(nn); L.rot_a = take(nn); L.rot_b = take(nn);
+  L.ktop_src = take(nn); L.ktop_k = take(nn); L.kbot_src = take(nn); L.kbot_k = take(nn);
   L.cnt = take(2LL * dc_max_nodes(n, kLeafMax) + 8);
   L.slab = off;
   if (out) *out = L;
@@ -673,18 +693,23 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     for (int b = 0; b < batch; ++b)
       for (size_t g = 0; g < nodes.size(); ++g) {
         const DcNode& nd = nodes[g];
-        GemmDesc D{};
-        D.a = q_old + (size_t)b * stride_q + nd.lo;
-        D.sa_i = 1; D.sa_k = n;
-        D.a_kidx = reinterpret_cast<const int*>(d_dc_ws + (size_t)b * DL.slab + DL.src) + nd.lo;
-        D.b = d_u + (size_t)b * stride_q + (size_t)nd.lo * n + nd.lo;
-        D.sb_k = 1; D.sb_j = n;
-        D.c = q_new + (size_t)b * stride_q + nd.lo;
-        D.ldc = n;
-        D.c_jidx = reinterpret_cast<const int*>(d_dc_ws + (size_t)b * DL.slab + DL.dest) + nd.lo;
-        D.m = nd.hi - nd.lo; D.n = 0; D.k = 0;
-        D.alpha = 1.0; D.beta = 0.0;
-        h_descs.push_back(D);
+        auto ip = [&](long long off) { return reinterpret_cast<const int*>(d_dc_ws + (size_t)b * DL.slab + off) + nd.lo; };
+        for (int half = 0; half < 2; ++half) {
+          const int r0 = half == 0 ? nd.lo : nd.mid;
+          GemmDesc D{};
+          D.a = q_old + (size_t)b * stride_q + r0;
+          D.sa_i = 1; D.sa_k = n;
+          D.a_kidx = ip(half == 0 ? DL.ktop_src : DL.kbot_src);
+          D.b = d_u + (size_t)b * stride_q + (size_t)nd.lo * n + nd.lo;
+          D.sb_k = 1; D.sb_j = n;
+          D.b_kidx = ip(half == 0 ? DL.ktop_k : DL.kbot_k);
+          D.c = q_new + (size_t)b * stride_q + r0;
+          D.ldc = n;
+          D.c_jidx = ip(DL.dest);
+          D.m = half == 0 ? nd.mid - nd.lo : nd.hi - nd.mid; D.n = 0; D.k = 0;
+          D.alpha = 1.0; D.beta = 0.0;
+          h_descs.push_back(D);
+        }
       }
   }
   if (!h_descs.empty())
@@ -718,7 +743,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                        dim3(256), 0, st, dn, q_old, stride_q, n);
     {
       const int use_lds = maxN <= kLdsCapSetup ? 1 : 0;
-      const size_t lds = use_lds ? (size_t)maxN * 20 + 16 : 0;
+      const size_t lds = use_lds ? (size_t)maxN * 21 + 32 : 0;
       const int threads = maxN >= 1024 ? 1024 : (maxN >= 256 ? 256 : 64);
       hipLaunchKernelGGL(k_dc_setup, dim3((unsigned)G, (unsigned)batch), dim3(threads), lds, st, d_dc_ws, DL,
                          dn, G, q_old, stride_q, w_old, descs, use_lds, d_big, (long long)3 * n);
@@ -741,7 +766,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                        dim3(256), 0, st, d_dc_ws, DL, dn, w_new);
     hipLaunchKernelGGL(k_dc_copy_deflated, dim3((unsigned)maxN, (unsigned)G, (unsigned)batch), dim3(256), 0, st,
                        d_dc_ws, DL, dn, q_old, q_new, stride_q);
-    SC_TRY(launch_gemm_f64(ctx, descs, G * batch, maxN, maxN, kGemmTile));
+    SC_TRY(launch_gemm_f64(ctx, descs, 2 * G * batch, (maxN + 1) / 2, maxN, kGemmTile, 1, /*gather=*/true));
   }
   const long long w_final = (nlev % 2 == 0) ? DL.w0 : DL.w1;
   hipLaunchKernelGGL(k_dc_unscale, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st,
