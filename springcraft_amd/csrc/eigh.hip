@@ -12,14 +12,14 @@
 namespace {
 
 // Tridiagonalisation panel width nb (SYR2K inner dimension K = 2 nb).  Measured on MI355X, N = 2000 C-alpha,
-// 8 structures in flight (profiles/r01_panel_width.txt): nb = 64: SYR2K 27.5 TFLOP/s (35 % of the 78.6 TFLOP/s
-// f64-MFMA peak), 52.7k modes/s; nb = 96: 31.7 TFLOP/s (40 %), 51.9k; nb = 128: 34.1 TFLOP/s (43 %), 50.7k
-// (wider panels make the per-column kernels read more V / W).  Default 96; SPRINGCRAFT_NB = 32|64|96|128 overrides.
+// 16 structures in flight (profiles/r01_panel_width.txt): nb = 64: SYR2K 32.2 TFLOP/s (41 % of the 78.6 TFLOP/s
+// f64-MFMA peak), 57.8k modes/s; nb = 96: 36.5 TFLOP/s (46 %), 56.8k; nb = 128: 38.3 TFLOP/s (49 %), 55.4k
+// (wider panels make the per-column kernels read more V / W).  Default 64; SPRINGCRAFT_NB = 32|64|96|128 overrides.
 int panel_width() {
   static int nb = [] {
     const char* e = getenv("SPRINGCRAFT_NB");
-    const int v = e ? atoi(e) : 96;
-    return (v == 128 || v == 96 || v == 64 || v == 32) ? v : 96;
+    const int v = e ? atoi(e) : 64;
+    return (v == 128 || v == 96 || v == 64 || v == 32) ? v : 64;
   }();
   return nb;
 }
