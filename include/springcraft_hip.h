@@ -208,6 +208,32 @@ int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors);
 int sc_ctx_set_profiling(sc_ctx* ctx, int enabled);
 int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
 
+/* ---- device-resident eigenpairs and their consumers ----------------------------------
+ * An sc_modes object holds all n eigenvalues and eigenvectors of one model's Kirchhoff (dim 1) or Hessian
+ * (dim 3) matrix in device memory, so that the quantities the reference derives from nma.eigen
+ * (nma.py:66-105 frequencies, :108-184 mean_square_fluctuation, :187-230 bfactor, :233-359 dcc, :476-524 prs)
+ * are computed without solving again and without moving the (n, n) eigenvector matrix over PCIe.
+ * It belongs to the context it was created with and must be destroyed before that context. */
+typedef struct sc_modes sc_modes;
+
+/* Assemble the ANM Hessian (dim 3) / GNM Kirchhoff matrix (dim 1) from coordinates and solve it, all on device
+ * (same arguments as sc_anm_eigen_f64 / sc_gnm_eigen_f64). */
+int sc_modes_from_coord(sc_ctx* ctx, const double* coord, int64_t n_atoms, int dim, const sc_ff_desc* ff,
+                        const sc_patch_desc* patch, const double* inv_sqrt_mass, sc_modes** out);
+/* Solve a host matrix (n, n) (lower triangle read, as numpy.linalg.eigh at nma.py:61); n must be a multiple of dim. */
+int sc_modes_from_matrix(sc_ctx* ctx, const double* a, int64_t n, int dim, sc_modes** out);
+void sc_modes_destroy(sc_modes* modes);
+int64_t sc_modes_order(const sc_modes* modes);
+/* Copy out: w (n) ascending, v (n, n) rows = modes (either may be NULL). */
+int sc_modes_get(sc_modes* modes, double* w, double* v);
+/* out (n / dim): sum over the k listed modes of v^2 / w, summed over the dim components of every atom. */
+int sc_modes_msf(sc_modes* modes, const int64_t* mode_idx, int64_t k, double* out);
+/* out (n / dim, n / dim): sum over the listed modes of <v_a, v_b> / w; norm != 0 divides by sqrt(c_aa c_bb). */
+int sc_modes_dcc(sc_modes* modes, const int64_t* mode_idx, int64_t k, int norm, double* out);
+/* ANM only. out (n / 3, n / 3) row-major: sums of the squared 3x3 blocks of pinv(H, rcond) (numpy hermitian
+ * rule); norm != 0 divides row a by out[a, a]. */
+int sc_modes_prs(sc_modes* modes, double rcond, int norm, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,8 @@ EXPORTED_SYMBOLS = [
     "sc_anm_eigen_f64", "sc_gnm_eigen_f64", "sc_dev_kirchhoff_f64", "sc_dev_hessian_f64",
     "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
     "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
+    "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
+    "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs",
 ]
 
 
@@ -135,6 +137,14 @@ def lib():
         "sc_dev_eigh_range_f64": (i32, [vp, vp, i64, i64, i64, i64, vp, vp]),
         "sc_ctx_set_profiling": (i32, [vp, i32]),
         "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
+        "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
+        "sc_modes_from_matrix": (i32, [vp, vp, i64, i32, P(vp)]),
+        "sc_modes_destroy": (None, [vp]),
+        "sc_modes_order": (i64, [vp]),
+        "sc_modes_get": (i32, [vp, vp, vp]),
+        "sc_modes_msf": (i32, [vp, vp, i64, vp]),
+        "sc_modes_dcc": (i32, [vp, vp, i64, i32, vp]),
+        "sc_modes_prs": (i32, [vp, dbl, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -193,6 +203,82 @@ class Context:
     def close(self):
         if self._h is not None and self._h.value:
             self._L.sc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Modes:
+    """
+    Owns one ``sc_modes``: all eigenpairs of a model, resident in device memory, plus the consumers that
+    work on them there (msf, dcc, prs).  ``dim`` is 1 for a GNM and 3 for an ANM.
+    """
+
+    def __init__(self, ctx, handle, dim):
+        self._ctx = ctx
+        self._h = handle
+        self._L = lib()
+        self.dim = dim
+        self.order = int(self._L.sc_modes_order(handle))
+
+    @classmethod
+    def from_coord(cls, ctx, coord, dim, ff_desc, patch_desc, inv_sqrt_mass):
+        h = C.c_void_p()
+        pd = C.byref(patch_desc) if patch_desc is not None else None
+        ctx.check(lib().sc_modes_from_coord(ctx.handle, ptr(coord), len(coord), dim, C.byref(ff_desc), pd,
+                                            ptr(inv_sqrt_mass), C.byref(h)))
+        return cls(ctx, h, dim)
+
+    @classmethod
+    def from_matrix(cls, ctx, matrix, dim):
+        a = np.ascontiguousarray(matrix, dtype=np.float64)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError(f"Expected a square matrix, got shape {a.shape}")
+        h = C.c_void_p()
+        ctx.check(lib().sc_modes_from_matrix(ctx.handle, ptr(a), a.shape[0], dim, C.byref(h)))
+        return cls(ctx, h, dim)
+
+    def values(self):
+        w = np.empty(self.order)
+        self._ctx.check(self._L.sc_modes_get(self._h, ptr(w), None))
+        return w
+
+    def eigen(self):
+        w = np.empty(self.order)
+        v = np.empty((self.order, self.order))
+        self._ctx.check(self._L.sc_modes_get(self._h, ptr(w), ptr(v)))
+        return w, v
+
+    @staticmethod
+    def _index_list(mode_idx):
+        return np.ascontiguousarray(mode_idx, dtype=np.int64).ravel()
+
+    def msf(self, mode_idx):
+        idx = self._index_list(mode_idx)
+        out = np.empty(self.order // self.dim)
+        self._ctx.check(self._L.sc_modes_msf(self._h, ptr(idx), len(idx), ptr(out)))
+        return out
+
+    def dcc(self, mode_idx, norm):
+        idx = self._index_list(mode_idx)
+        n = self.order // self.dim
+        out = np.empty((n, n))
+        self._ctx.check(self._L.sc_modes_dcc(self._h, ptr(idx), len(idx), int(bool(norm)), ptr(out)))
+        return out
+
+    def prs(self, rcond, norm):
+        n = self.order // 3
+        out = np.empty((n, n))
+        self._ctx.check(self._L.sc_modes_prs(self._h, float(rcond), int(bool(norm)), ptr(out)))
+        return out
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._L.sc_modes_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

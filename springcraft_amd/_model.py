@@ -60,6 +60,7 @@ class ElasticNetworkModel:
         self._inv_sqrt_mass = None if self._masses is None else 1 / np.sqrt(self._masses)
         self._matrix = None
         self._covariance = None
+        self._modes = None   # device-resident eigenpairs, only while no host matrix exists (see _modes_device)
 
     @property
     def masses(self):
@@ -70,6 +71,9 @@ class ElasticNetworkModel:
 
     # ---- matrix <-> covariance, lazily cached (anm.py:105-148) --------------------------------
     def _get_matrix(self):
+        # the matrix object handed out may be edited in place (anm.py:53 "not a copy"), so cached eigenpairs
+        # cannot be trusted from here on
+        self._modes = None
         if self._matrix is None:
             if self._covariance is None:
                 self._matrix, _ = _assemble(self._coord, self._ff, self._dim, self._inv_sqrt_mass)
@@ -85,8 +89,10 @@ class ElasticNetworkModel:
             raise error(f"Expected shape {(n, n)}, got {value.shape}")
         self._matrix = value
         self._covariance = None
+        self._modes = None
 
     def _get_covariance(self):
+        self._modes = None
         if self._covariance is None:
             from . import nma
 
@@ -99,8 +105,33 @@ class ElasticNetworkModel:
             raise IndexError(f"Expected shape {(n, n)}, got {value.shape}")
         self._covariance = value
         self._matrix = None
+        self._modes = None
 
     # ---- eigensolve ---------------------------------------------------------------------------
+    def _modes_device(self):
+        """
+        All eigenpairs as a device-resident :class:`_hip.Modes`.  While neither the matrix nor the covariance
+        has been handed out to the caller (so nobody can have edited it) and the force field is evaluated on
+        the device, the object is kept: ``eigen`` / ``frequencies`` / ``mean_square_fluctuation`` / ``dcc`` then
+        share ONE solve, where the reference solves again for each (nma.py:61 via :99, :161, :330).  Otherwise
+        the current host matrix is solved, every time, as the reference does.
+        """
+        if self._matrix is None and self._covariance is None:
+            if self._modes is not None:
+                return self._modes
+            ff_desc, patch, fused = device_plan(self._ff)
+            if fused:
+                coord = _validated_coord(self._coord, self._ff)
+                keep = []
+                patch_desc = _normalised_patch(patch, len(coord), keep)
+                ism = None
+                if self._inv_sqrt_mass is not None:
+                    ism = np.ascontiguousarray(self._inv_sqrt_mass, dtype=np.float64)
+                self._modes = _hip.Modes.from_coord(_hip.context(), coord, self._dim, ff_desc, patch_desc, ism)
+                return self._modes
+        matrix = self._get_matrix()
+        return _hip.Modes.from_matrix(_hip.context(), matrix, self._dim)
+
     def _eigen_device(self, subset_by_index=None):
         """
         (eig_values, eig_vectors[rows]) on the device.  When the matrix has not been materialised
@@ -136,23 +167,7 @@ class ElasticNetworkModel:
             return nma.eigh(self._get_matrix(), subset_by_index=(lo, hi))
 
         if self._matrix is None and self._covariance is None:
-            ff_desc, patch, fused = device_plan(self._ff)
+            _, _, fused = device_plan(self._ff)
             if fused:
-                coord = _validated_coord(self._coord, self._ff)
-                n = len(coord)
-                keep = []
-                patch_desc = _normalised_patch(patch, n, keep)
-                pd = C.byref(patch_desc) if patch_desc is not None else None
-                ctx = _hip.context()
-                L = _hip.lib()
-                m = n * self._dim
-                w = np.empty(m)
-                v = np.empty((m, m))
-                ism = None
-                if self._inv_sqrt_mass is not None:
-                    ism = np.ascontiguousarray(self._inv_sqrt_mass, dtype=np.float64)
-                fn = L.sc_anm_eigen_f64 if self._dim == 3 else L.sc_gnm_eigen_f64
-                ctx.check(fn(ctx.handle, _hip.ptr(coord), n, C.byref(ff_desc), pd, _hip.ptr(ism),
-                             _hip.ptr(w), _hip.ptr(v)))
-                return w, v
+                return self._modes_device().eigen()
         return nma.eigh(self._get_matrix())

@@ -1,10 +1,12 @@
 // C-ABI entry points of libspringcraft_hip.so (declared in include/springcraft_hip.h).
 // Host-side plumbing only: argument validation, patch-table construction, transfers and
 // kernel sequencing.  All arithmetic lives in assembly.hip / the eigensolver units.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <map>
+#include <new>
 #include <utility>
 
 #include "common.h"
@@ -650,6 +652,190 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
 int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors) {
   if (n <= 0 || batch <= 0) return 0;
   return (int64_t)eigh_workspace_bytes(n, batch, want_vectors != 0);
+}
+
+// ---- device-resident eigenpairs --------------------------------------------------------------------------
+}  // extern "C"
+
+struct sc_modes {
+  sc_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int dim = 1;
+  double* d_w = nullptr;
+  double* d_v = nullptr;
+};
+
+namespace {
+int modes_alloc(sc_ctx* ctx, int64_t n, int dim, sc_modes** out) {
+  sc_modes* m = new (std::nothrow) sc_modes();
+  if (!m) return sc_set_error(ctx, SC_ERR_NOMEM, "out of host memory");
+  m->ctx = ctx; m->n = n; m->dim = dim;
+  if (hipMalloc(&m->d_w, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess ||
+      hipMalloc(&m->d_v, sizeof(double) * (size_t)std::max<int64_t>(n * n, 1)) != hipSuccess) {
+    (void)hipFree(m->d_w);
+    delete m;
+    return sc_set_error(ctx, SC_ERR_NOMEM, "cannot allocate %lld x %lld eigenvectors on the device", (long long)n,
+                        (long long)n);
+  }
+  *out = m;
+  return SC_OK;
+}
+
+// mode list -> validated int32 list on the device (in scratch)
+int stage_mode_list(sc_modes* m, const int64_t* idx, int64_t k, int* d_sel) {
+  sc_ctx* ctx = m->ctx;
+  std::vector<int> h((size_t)k);
+  for (int64_t i = 0; i < k; ++i) {
+    int64_t v = idx[i];
+    if (v < 0) v += m->n;   // NumPy-style negative indices
+    if (v < 0 || v >= m->n)
+      return sc_set_error(ctx, SC_ERR_INDEX, "mode index %lld out of bounds for %lld modes", (long long)idx[i],
+                          (long long)m->n);
+    h[(size_t)i] = (int)v;
+  }
+  if (k > 0) {
+    SC_HIP(ctx, hipMemcpyAsync(d_sel, h.data(), (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
+  }
+  return SC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sc_modes_from_coord(sc_ctx* ctx, const double* coord, int64_t n, int dim, const sc_ff_desc* ff,
+                        const sc_patch_desc* patch, const double* inv_sqrt_mass, sc_modes** out) {
+  SC_TRY(check_coord_args(ctx, coord, n));
+  SC_TRY(check_ff(ctx, ff));
+  if (!out || (dim != 1 && dim != 3)) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = n * dim;
+  const size_t elems = (size_t)m * m;
+  sc_modes* md = nullptr;
+  SC_TRY(modes_alloc(ctx, m, dim, &md));
+  int rc = SC_OK;
+  if (n > 0) {
+    Staged st;
+    Bump bump{};
+    rc = stage_inputs(ctx, coord, n, ff, patch, inv_sqrt_mass, elems * 8 + 2048, st, bump);
+    if (rc == SC_OK) {
+      double* d_m = bump.take<double>(elems);
+      const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
+      rc = dim == 1 ? launch_kirchhoff(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m, nullptr)
+                    : launch_hessian(ctx, st.d_coord, n, 1, st.ff_dev, pdev, st.d_w, d_m);
+      if (rc == SC_OK) rc = eigh_batched(ctx, d_m, m, 1, md->d_w, md->d_v);
+      if (rc == SC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = sc_set_error(ctx, SC_ERR_HIP, "eigensolve failed");
+    }
+  }
+  if (rc != SC_OK) { sc_modes_destroy(md); return rc; }
+  *out = md;
+  return SC_OK;
+}
+
+int sc_modes_from_matrix(sc_ctx* ctx, const double* a, int64_t n, int dim, sc_modes** out) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && !a) || !out || (dim != 1 && dim != 3) || n % dim != 0)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  sc_modes* md = nullptr;
+  SC_TRY(modes_alloc(ctx, n, dim, &md));
+  int rc = SC_OK;
+  if (n > 0) {
+    const size_t elems = (size_t)n * n;
+    rc = sc_reserve_scratch(ctx, elems * 8 + 1024);
+    if (rc == SC_OK) {
+      double* d_a = reinterpret_cast<double*>(ctx->scratch);
+      if (hipMemcpyAsync(d_a, a, elems * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = sc_set_error(ctx, SC_ERR_HIP, "upload failed");
+      if (rc == SC_OK) rc = eigh_batched(ctx, d_a, n, 1, md->d_w, md->d_v);
+      if (rc == SC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = sc_set_error(ctx, SC_ERR_HIP, "eigensolve failed");
+    }
+  }
+  if (rc != SC_OK) { sc_modes_destroy(md); return rc; }
+  *out = md;
+  return SC_OK;
+}
+
+void sc_modes_destroy(sc_modes* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipFree(m->d_w);
+  (void)hipFree(m->d_v);
+  delete m;
+}
+
+int64_t sc_modes_order(const sc_modes* m) { return m ? m->n : -1; }
+
+int sc_modes_get(sc_modes* m, double* w, double* v) {
+  if (!m) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = m->ctx;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (m->n == 0) return SC_OK;
+  if (w) SC_HIP(ctx, hipMemcpyAsync(w, m->d_w, (size_t)m->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (v) SC_HIP(ctx, hipMemcpyAsync(v, m->d_v, (size_t)m->n * m->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_modes_msf(sc_modes* m, const int64_t* mode_idx, int64_t k, double* out) {
+  if (!m) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = m->ctx;
+  if (k < 0 || (k > 0 && !mode_idx) || (m->n > 0 && !out)) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (m->n == 0) return SC_OK;
+  const size_t N = (size_t)(m->n / m->dim);
+  const size_t work = modes_scratch_bytes(m->n, m->dim, k, 0);
+  SC_TRY(sc_reserve_scratch(ctx, work + align_up((size_t)k * 4, 256) + align_up(N * 8, 256) + 1024));
+  Bump bump{(char*)ctx->scratch};
+  int* d_sel = bump.take<int>((size_t)std::max<int64_t>(k, 1));
+  double* d_out = bump.take<double>(N);
+  char* scratch = bump.take<char>(work);
+  SC_TRY(stage_mode_list(m, mode_idx, k, d_sel));
+  SC_TRY(modes_msf_device(ctx, m->d_v, m->d_w, m->n, m->dim, d_sel, k, scratch, d_out));
+  SC_HIP(ctx, hipMemcpyAsync(out, d_out, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_modes_dcc(sc_modes* m, const int64_t* mode_idx, int64_t k, int norm, double* out) {
+  if (!m) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = m->ctx;
+  if (k < 0 || (k > 0 && !mode_idx) || (m->n > 0 && !out)) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (m->n == 0) return SC_OK;
+  const size_t N = (size_t)(m->n / m->dim);
+  const size_t work = modes_scratch_bytes(m->n, m->dim, k, 1);
+  SC_TRY(sc_reserve_scratch(ctx, work + align_up((size_t)k * 4, 256) + align_up(N * N * 8, 256) + 1024));
+  Bump bump{(char*)ctx->scratch};
+  int* d_sel = bump.take<int>((size_t)std::max<int64_t>(k, 1));
+  double* d_out = bump.take<double>(N * N);
+  char* scratch = bump.take<char>(work);
+  SC_TRY(stage_mode_list(m, mode_idx, k, d_sel));
+  SC_TRY(modes_dcc_device(ctx, m->d_v, m->d_w, m->n, m->dim, d_sel, k, norm, scratch, d_out));
+  SC_HIP(ctx, hipMemcpyAsync(out, d_out, N * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_modes_prs(sc_modes* m, double rcond, int norm, double* out) {
+  if (!m) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = m->ctx;
+  if (m->dim != 3) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "perturbation response scanning needs an ANM (dim 3)");
+  if (m->n > 0 && !out) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  if (m->n == 0) return SC_OK;
+  const size_t N = (size_t)(m->n / 3);
+  const size_t work = modes_scratch_bytes(m->n, 3, m->n, 2);
+  SC_TRY(sc_reserve_scratch(ctx, work + align_up(N * N * 8, 256) + 1024));
+  Bump bump{(char*)ctx->scratch};
+  double* d_out = bump.take<double>(N * N);
+  char* scratch = bump.take<char>(work);
+  SC_TRY(modes_prs_device(ctx, m->d_v, m->d_w, m->n, rcond, norm, scratch, d_out));
+  SC_HIP(ctx, hipMemcpyAsync(out, d_out, N * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
 }
 
 }  // extern "C"

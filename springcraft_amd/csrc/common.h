@@ -94,3 +94,13 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64
                        double* d_w, double* d_v);
 // Hermitian pseudo-inverse of the (n,n) matrix d_a (destroyed) into d_out, numpy.linalg.pinv(hermitian=True) rule.
 int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n, double rcond, double* d_out);
+
+// ---- mode-subset consumers on device-resident eigenpairs (consumers.hip) ------------------------------
+// what: 0 = msf, 1 = dcc, 2 = prs
+size_t modes_scratch_bytes(int64_t n, int dim, int64_t nsel, int what);
+int modes_msf_device(sc_ctx* ctx, const double* d_v, const double* d_w, int64_t n, int dim, const int* d_sel,
+                     int64_t nsel, char* scratch, double* d_out);
+int modes_dcc_device(sc_ctx* ctx, const double* d_v, const double* d_w, int64_t n, int dim, const int* d_sel,
+                     int64_t nsel, int norm, char* scratch, double* d_out);
+int modes_prs_device(sc_ctx* ctx, const double* d_v, const double* d_w, int64_t n, double rcond, int norm,
+                     char* scratch, double* d_out);

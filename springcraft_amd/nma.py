@@ -3,9 +3,11 @@ Normal-mode analysis on top of the device eigensolver.
 
 ``eigen`` is the hot-path function (reference: nma.py:29-63): a dense symmetric float64
 eigendecomposition, here performed by the hand-written HIP solver (``csrc/eigh*.hip``) instead
-of LAPACK ``dsyevd``.  The remaining functions are thin NumPy consumers of its output
-(reference: nma.py:66-569); they are outside the accelerated path and kept so that analyses
-written against springcraft keep working.
+of LAPACK ``dsyevd``.  The mode-subset consumers (``frequencies``, ``mean_square_fluctuation``,
+``bfactor``, ``dcc``, ``prs``; reference: nma.py:66-359, :476-524) run on the device-resident
+eigenpairs (``csrc/consumers.hip``): the (n, n) eigenvector matrix never crosses PCIe for them.
+``normal_mode``, ``linear_response`` and ``effector_sensor`` are O(n) / O(n^2) host arithmetic on
+results that are already on the host.
 """
 
 import ctypes as C
@@ -92,8 +94,7 @@ def eigen(enm, subset_by_index=None):
 def frequencies(enm):
     """Frequencies sqrt(lambda)/(2 pi) of all modes; trivial eigenvalues enter as |lambda| (nma.py:66-105)."""
     _, ntriv = _model_kind(enm)
-    w, _ = eigen(enm)
-    w = np.array(w)
+    w = enm._modes_device().values()
     w[:ntriv] = np.abs(w[:ntriv])
     return np.sqrt(w) / (2 * np.pi)
 
@@ -110,12 +111,9 @@ def _mode_selection(enm, mode_subset, n_modes):
 
 def mean_square_fluctuation(enm, mode_subset=None, tem=None, tem_factors=K_B):
     """Per-atom mean square fluctuation sum_k v_k^2 / lambda_k over the selected modes (nma.py:108-184)."""
-    kind, _ = _model_kind(enm)
-    w, v = eigen(enm)
-    sel = _mode_selection(enm, mode_subset, len(w))
-    contrib = (v[sel] ** 2 / w[sel, None]).sum(axis=0)
-    if kind == "anm":
-        contrib = contrib.reshape(-1, 3).sum(axis=1)
+    _model_kind(enm)
+    modes = enm._modes_device()
+    contrib = modes.msf(_mode_selection(enm, mode_subset, modes.order))
     if tem is not None:
         contrib = contrib * (tem * tem_factors)
     return contrib
@@ -128,17 +126,10 @@ def bfactor(enm, mode_subset=None, tem=None, tem_factors=K_B):
 
 def dcc(enm, mode_subset=None, norm=True, tem=None, tem_factors=K_B):
     """Dynamic cross-correlation between nodes over the selected modes (nma.py:233-359)."""
-    kind, _ = _model_kind(enm)
-    w, v = eigen(enm)
-    sel = _mode_selection(enm, mode_subset, len(w))
-    vs = v[sel]
-    cov = (vs.T / w[sel]) @ vs  # sum_k v_k v_k^T / lambda_k
-    if kind == "anm":
-        n = cov.shape[0] // 3
-        cov = cov.reshape(n, 3, n, 3).trace(axis1=1, axis2=3)
-    if norm:
-        d = np.sqrt(np.diag(cov))
-        cov = cov / np.outer(d, d)
+    _model_kind(enm)
+    modes = enm._modes_device()
+    # sum_k <v_k[a], v_k[b]> / lambda_k, normalised by sqrt(c_aa c_bb) on request
+    cov = modes.dcc(_mode_selection(enm, mode_subset, modes.order), norm)
     if tem is not None:  # applied after the normalisation, as the reference does (nma.py:355-357)
         cov = cov * tem * tem_factors
     return cov
@@ -190,12 +181,16 @@ def prs(anm, norm=True):
 
     if not isinstance(anm, ANM):
         raise ValueError("Instance of ANM class expected.")
-    c2 = anm.covariance**2
-    n = c2.shape[0] // 3
-    mat = c2.reshape(n, 3, n, 3).sum(axis=(1, 3))
-    if norm:
-        mat = mat / np.diag(mat)[:, None]
-    return mat
+    if anm._covariance is not None:
+        # a covariance the caller assigned (or already fetched): reduce that very matrix
+        c2 = anm._covariance**2
+        n = c2.shape[0] // 3
+        mat = c2.reshape(n, 3, n, 3).sum(axis=(1, 3))
+        if norm:
+            mat = mat / np.diag(mat)[:, None]
+        return mat
+    # covariance = pinv(hessian, rcond=1e-6) (anm.py:114-117) formed and reduced on the device
+    return anm._modes_device().prs(1e-6, norm)
 
 
 def effector_sensor(prs_matrix):
