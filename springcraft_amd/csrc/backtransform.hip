@@ -23,18 +23,18 @@ constexpr int kNbt = 128;
 constexpr int kGramSplits = 4;
 
 __global__ __launch_bounds__(256) void k_bt_clean(double* __restrict__ a_all, long long stride_a, int n,
-                                                  int nbt, int nref) {
+                                                  int nbt, int nref, int off) {
   double* A = a_all + (size_t)blockIdx.y * stride_a;
   const int cs = blockIdx.x * nbt;
-  // (a) triangle above the unit entries: rows cs+1 .. c of column c, for c in the block
+  // (a) triangle above the unit entries: rows cs+off .. c+off-1 of column c, for c in the block
   for (int idx = threadIdx.x; idx < nbt * nbt; idx += blockDim.x) {
-    const int q = idx / nbt, rr = idx % nbt;  // column cs+q, row cs+1+rr
-    const int c = cs + q, r = cs + 1 + rr;
-    if (c < n && r < n && r <= c) A[(size_t)c * n + r] = 0.0;
+    const int q = idx / nbt, rr = idx % nbt;  // column cs+q, row cs+off+rr
+    const int c = cs + q, r = cs + off + rr;
+    if (c < n && r < n && r < c + off) A[(size_t)c * n + r] = 0.0;
   }
-  // (b) columns without a reflector (c >= nref = n-2): zero rows cs+1 ..
+  // (b) columns without a reflector (c >= nref): zero rows cs+off ..
   for (int c = std::max(cs, nref); c < std::min(cs + nbt, n); ++c)
-    for (int r = cs + 1 + threadIdx.x; r < n; r += blockDim.x) A[(size_t)c * n + r] = 0.0;
+    for (int r = cs + off + threadIdx.x; r < n; r += blockDim.x) A[(size_t)c * n + r] = 0.0;
 }
 
 // T (upper triangular, nbt x nbt, column-major) from the Gram slices and tau; grid (block, matrix).
@@ -122,9 +122,9 @@ int bt_desc_count(int n, int batch) {
 // d_a is modified (cleaned); d_vt: (batch, n, n) scratch that receives V T.
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, const double* d_tri_ws,
                           const TriLayout& TL, double* d_bt_ws, const BtLayout& BL, double* d_z,
-                          long long stride_z, int ncols, double* d_vt, GemmDesc* d_descs) {
+                          long long stride_z, int ncols, double* d_vt, GemmDesc* d_descs, int off) {
   hipStream_t st = ctx->stream;
-  const int nref = n - 2;  // reflector columns 0 .. n-3
+  const int nref = n - 1 - off;  // reflector columns 0 .. nref-1 (a reflector needs two rows)
   if (nref <= 0) return SC_OK;
   const int nbt = BL.nbt;
   const int npanels = (nref + nbt - 1) / nbt;
@@ -135,12 +135,12 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   std::vector<GemmDesc> h(4 * grp);
   for (int p = 0; p < npanels; ++p) {
     const int cs = p * nbt;
-    const int mrow = n - cs - 1;
+    const int mrow = n - cs - off;
     const int pc = std::min(nbt, n - cs);   // columns of this block that exist in the matrix
     for (int b = 0; b < batch; ++b) {
       double* bt = d_bt_ws + (size_t)b * BL.slab;
-      const double* vp = d_a + (size_t)b * stride_a + (size_t)cs * n + cs + 1;
-      double* vtp = d_vt + (size_t)b * stride_a + (size_t)cs * n + cs + 1;
+      const double* vp = d_a + (size_t)b * stride_a + (size_t)cs * n + cs + off;
+      double* vtp = d_vt + (size_t)b * stride_a + (size_t)cs * n + cs + off;
       double* tp = bt + BL.t + (size_t)p * nbt * nbt;
       GemmDesc G{};   // G_p = V^T V, split-K slices
       G.a = vp; G.sa_i = n; G.sa_k = 1;
@@ -159,7 +159,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       h[1 * grp + (size_t)p * batch + b] = V;
       GemmDesc W{};   // W1 = V^T Z[rows], split-K slices
       W.a = vp; W.sa_i = n; W.sa_k = 1;
-      W.b = d_z + (size_t)b * stride_z + cs + 1; W.sb_k = 1; W.sb_j = n;
+      W.b = d_z + (size_t)b * stride_z + cs + off; W.sb_k = 1; W.sb_j = n;
       W.c = bt + BL.w1; W.ldc = nbt;
       W.m = pc; W.n = ncols; W.k = mrow;
       W.alpha = 1.0; W.beta = 0.0;
@@ -168,7 +168,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       GemmDesc U{};   // Z[rows] -= VT W
       U.a = vtp; U.sa_i = 1; U.sa_k = n;
       U.b = bt + BL.w2; U.sb_k = 1; U.sb_j = nbt;
-      U.c = d_z + (size_t)b * stride_z + cs + 1; U.ldc = n;
+      U.c = d_z + (size_t)b * stride_z + cs + off; U.ldc = n;
       U.m = mrow; U.n = ncols; U.k = pc;
       U.alpha = -1.0; U.beta = 1.0;
       h[3 * grp + (size_t)p * batch + b] = U;
@@ -177,14 +177,14 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
 
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
-                     nref);
+                     nref, off);
   SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g));
   hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)npanels, (unsigned)batch), dim3(256),
                      sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
   SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile));
 
   for (int p = npanels - 1; p >= 0; --p) {
-    const int mrow = n - p * nbt - 1;
+    const int mrow = n - p * nbt - off;
     SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s));
     hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
     SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile));

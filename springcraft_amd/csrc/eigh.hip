@@ -48,12 +48,32 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
   return (size_t)off;
 }
 
+// Two-stage tridiagonalisation (twostage.hip) instead of the one-stage panel algorithm: SPRINGCRAFT_TWO_STAGE=1
+// forces it on, =0 off; by default matrices of order >= SPRINGCRAFT_TWO_STAGE_MIN use it.
+bool two_stage_for(int n) {
+  static const int mode = [] {
+    const char* e = getenv("SPRINGCRAFT_TWO_STAGE");
+    return e ? atoi(e) : -1;
+  }();
+  static const int min_n = [] {
+    const char* e = getenv("SPRINGCRAFT_TWO_STAGE_MIN");
+    return e ? atoi(e) : 1 << 30;
+  }();
+  if (n < 4 * sb_band_width()) return false;
+  if (mode == 0) return false;
+  if (mode == 1) return true;
+  return n >= min_n;
+}
+
 struct Plan {
   TriLayout TL;
   DcLayout DL;
   BtLayout BL;
-  size_t off_tri = 0, off_dc = 0, off_bt = 0, off_qtmp = 0, off_u = 0, off_desc = 0, total = 0;
+  SbLayout SL;
+  bool two = false;
+  size_t off_tri = 0, off_dc = 0, off_bt = 0, off_qtmp = 0, off_u = 0, off_desc = 0, off_sb = 0, off_dia = 0, total = 0;
   int n_syr2k = 0, n_merge = 0, n_bt = 0;
+  long long n_bt2 = 0;
 };
 
 Plan make_plan(int n, int batch, bool vectors) {
@@ -63,6 +83,13 @@ Plan make_plan(int n, int batch, bool vectors) {
   P.off_tri = take(tri_slab_doubles(n, &P.TL) * 8 * batch);
   const int npanels = (n + kNb - 1) / kNb;
   P.n_syr2k = npanels * batch;
+  P.two = two_stage_for(n);
+  if (P.two) {
+    P.off_sb = take(sb_slab_doubles(n, vectors ? n : 0, &P.SL) * 8 * batch);
+    P.off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
+    P.n_syr2k = std::max(P.n_syr2k, sb_desc_count(n, batch));
+    if (vectors) P.n_bt2 = sb_bt2_desc_count(n, batch);
+  }
   if (vectors) {
     P.off_dc = take(dc_slab_doubles(n, &P.DL) * 8 * batch);
     P.off_bt = take(bt_slab_doubles(n, &P.BL) * 8 * batch);
@@ -71,7 +98,7 @@ Plan make_plan(int n, int batch, bool vectors) {
     P.n_merge = 2 * dc_max_nodes(n, P.DL.leaf_max) * batch;   // two half-GEMMs per merge
     P.n_bt = bt_desc_count(n, batch);
   }
-  P.off_desc = take(sizeof(GemmDesc) * ((size_t)P.n_syr2k + P.n_merge + P.n_bt + 8));
+  P.off_desc = take(sizeof(GemmDesc) * ((size_t)P.n_syr2k + P.n_merge + P.n_bt + (size_t)P.n_bt2 + 8));
   P.total = off;
   return P;
 }
@@ -184,7 +211,15 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
   float ms_symv = 0.f, ms_syr2k = 0.f;
-  SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, descs, &ms_symv, &ms_syr2k));
+  double* sb_ws = (double*)(base + P.off_sb);
+  if (P.two) {
+    // [3] / [4] then carry the stage-1 / stage-2 times, [5] = 1 marks the two-stage path
+    SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
+    SC_TRY(sytrd_2stage_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, sb_ws, P.SL, (int*)(base + P.off_dia),
+                                descs, &ms_symv, &ms_syr2k));
+  } else {
+    SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, descs, &ms_symv, &ms_syr2k));
+  }
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
 
   if (!vectors) {
@@ -198,8 +233,10 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
+    if (P.two)
+      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, d_v, stride_a, n, descs + P.n_syr2k + P.n_merge + P.n_bt));
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
-                                 descs + P.n_syr2k + P.n_merge));
+                                 descs + P.n_syr2k + P.n_merge, P.two ? sb_band_width() : 1));
   }
   if (prof) {
     SC_HIP(ctx, hipEventRecord(ev[3], st));
@@ -213,7 +250,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     ctx->last_timings[2] = t23;
     ctx->last_timings[3] = ms_symv;
     ctx->last_timings[4] = ms_syr2k;
-    ctx->last_timings[5] = 0.0;
+    ctx->last_timings[5] = P.two ? 1.0 : 0.0;
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
   SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads

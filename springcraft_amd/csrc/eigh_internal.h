@@ -22,6 +22,9 @@ struct TriLayout {
 
 // d_a: (batch) n x n column-major, lower triangle valid after the mirror pass; on exit column c holds
 // v_c (explicit leading 1) in rows c+1.., and ws holds d, e, tau.
+// NumPy (row-major) lower triangle -> column-major lower triangle, in place
+int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch);
+
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv, float* ms_syr2k);
 
@@ -70,6 +73,7 @@ int sturm_bisect_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, 
 
 // ---- back-transformation -----------------------------------------------------------------------------
 // Z <- Q_H Z with the reflectors stored in d_a (see tridiag_batched) and tau in the tri slab.
+// off: row distance of a reflector's unit entry from the diagonal (1: one-stage; 64: stage 1 of the two-stage path).
 struct BtLayout {
   int n, nbt, splits;
   long long slab;
@@ -86,7 +90,39 @@ int bt_desc_count(int n, int batch);
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch,
                           const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws,
                           const BtLayout& BL, double* d_z, long long stride_z, int ncols, double* d_vt,
-                          GemmDesc* d_descs /* bt_desc_count(n, batch) records */);
+                          GemmDesc* d_descs /* bt_desc_count(n, batch) records */, int off = 1);
+
+// ---- two-stage tridiagonalisation (twostage.hip) ----------------------------------------------------------------
+struct SbLayout {
+  int n;
+  long long slab;
+  long long vw, wv;   // [V|W], [W|V] panels, n x 128
+  long long xv;       // [X1|X2|V], n x 192
+  long long qrpart, qrpiv;   // panel-QR partial Gram rows / pivot row (two copies each)
+  long long small;    // split-K slices of V^T [X1|X2|V]
+  long long cmat;     // [T; T; -S/2], 192 x 64
+  long long ab;       // band storage 128 x n
+  int ngroups;        // sweep groups (64 sweeps each)
+  long long ndia;     // diamonds
+  int nslot;          // concurrently applied diamonds in the back-transformation
+  long long vd, vt2;  // diamonds V and V T: ndia x (128 x 64)
+  long long tau2;     // ndia x 64
+  long long w1;       // nslot x 64 x ncols
+};
+// ncols: columns of Z the back-transformation will be applied to (0: eigenvalues only)
+size_t sb_slab_doubles(int n, int ncols, SbLayout* out);
+int sb_desc_count(int n, int batch);
+long long sb_bt2_desc_count(int n, int batch);
+int sb_band_width();
+// d_a: column-major lower triangle valid.  On exit d, e (and the stage-1 tau) are in the tri slab, the stage-1
+// reflectors in A (unit entry of column c at row c + sb_band_width()), the stage-2 reflectors in the sb slab.
+int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_tri_ws,
+                         const TriLayout& TL, double* d_sb_ws, const SbLayout& SL, int* d_dia_off /* n/64 + 2 ints */,
+                         GemmDesc* d_descs /* sb_desc_count */, float* ms_stage1, float* ms_stage2,
+                         double* d_band_copy = nullptr);
+// Z <- Q2 Z (stage-2 reflectors)
+int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, double* d_z, long long stride_z,
+                int ncols, GemmDesc* d_descs /* sb_bt2_desc_count */);
 
 // ---- partial spectrum (stein.hip) -----------------------------------------------------------------------
 size_t stein_workspace_doubles(int n, int m);

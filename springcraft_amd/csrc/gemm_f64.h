@@ -30,6 +30,7 @@ struct GemmDesc {
   int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K)
   int row_off, col_off;
   long long split_stride; // split-K launches: slice s writes alpha*partial to C + s*split_stride (beta ignored)
+  int a_tri;              // launches with tri = true: 1: A(i,k) counts only for i >= k; 2: only for k > i
 };
 
 // Default block tile of the solver's GEMMs: 64 x 64 x 8 (tile id 3).  On gfx950 the f64 MFMA is slow enough
@@ -42,5 +43,6 @@ constexpr int kGemmTile = 3;
 // tile: 0 = 128x128x16 block tile, 1 = 64x128x16, 2 = 64x64x16, 3 = 64x64x8 (see kGemmTile).
 // split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
 // gather: the records carry a_kidx / b_kidx lists (D&C merges); uses the 64x64x8 tile whatever `tile` says.
+// tri: the records carry a_tri masks (lower-stored symmetric A; band reduction); 64x64x8 tile, no gathers.
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k = 1, bool gather = false);
+                    int split_k = 1, bool gather = false, bool tri = false);

@@ -23,7 +23,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int PAD = 16;
 
-template <int BM, int BN, int BK, int MINW, bool GATHER>
+template <int BM, int BN, int BK, int MINW, bool GATHER, bool TRI = false>
 __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
@@ -48,6 +48,11 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
     k_begin = slice * chunk;
     k_end = min(K, k_begin + chunk);
   }
+  // triangular A operand (TRI instantiation, the symmetric products of the band reduction): the block only walks
+  // the K range in which its rows have non-zero entries
+  const int tri = TRI ? D.a_tri : 0;
+  if (TRI && tri == 1) k_end = min(k_end, m0 + BM);
+  if (TRI && tri == 2) k_begin = max(k_begin, m0);
 
   const double* __restrict__ A = D.a;
   const double* __restrict__ B = D.b;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
         const int k = kt + kq + p * KSTEP;
         const int gi = m0 + i;
         double v = 0.0;
-        if (gi < M && k < k_end) {
+        if (gi < M && k < k_end && (!TRI || tri == 0 || (tri == 1 ? gi >= k : k > gi))) {
           const long long kk = (GATHER && kidx) ? (long long)kidx[k] : (long long)k;
           v = A[(long long)gi + kk * sa_k];
         }
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
       for (int p = 0; p < A_PER_THREAD; ++p) {
         const int gi = m0 + iq + p * ISTEP;
         const int gk = kt + k;
-        ra[p] = (gi < M && gk < k_end) ? A[(long long)gi * sa_i + gk] : 0.0;
+        ra[p] = (gi < M && gk < k_end && (!TRI || tri == 0 || (tri == 1 ? gi >= gk : gk > gi)))
+                    ? A[(long long)gi * sa_i + gk] : 0.0;
       }
     }
     // B tile: BK x BN
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
 }  // namespace
 
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k, bool gather) {
+                    int split_k, bool gather, bool tri) {
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
   const int bm = tile == 0 ? 128 : 64;
@@ -240,7 +246,9 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   const int bk = tile == 3 ? 8 : 16;
   dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(count * split_k));
   const size_t lds = sizeof(double) * 2 * bk * ((size_t)(bm + PAD) + (bn + PAD));
-  if (gather)   // only the default tile is instantiated with gather support
+  if (tri)      // triangular A operands: default tile only
+    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false, true>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  else if (gather)   // only the default tile is instantiated with gather support
     hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, true>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
   else if (tile == 1)
     hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);

@@ -446,6 +446,13 @@ __global__ void k_mirror_lower(double* __restrict__ a_all, long long stride_a, i
 
 }  // namespace
 
+int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch) {
+  dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 8), 0, ctx->stream, d_a, stride_a, n);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv,
                     float* ms_syr2k) {
@@ -453,10 +460,7 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
   const int nb = L.nb;
   // persistent SYMV grid: 4 resident blocks per CU (LDS-limited), shared by the matrices of the batch
   const int symv_blocks = 4 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
-  {
-    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)batch);
-    hipLaunchKernelGGL(k_mirror_lower, grid, dim3(32, 8), 0, st, d_a, stride_a, n);
-  }
+  SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   const bool prof = ctx->profiling && ms_symv && ms_syr2k;
   if (prof) {

@@ -1,0 +1,770 @@
+// Two-stage tridiagonalisation for large matrices (replaces the one-stage panel algorithm of tridiag.hip, whose
+// matrix-vector products are bound by HBM bandwidth: 4/3 n^3 bytes per matrix).
+//
+//   stage 1  sy2sb   dense -> band of half-width kB = 64.  Per 64-column panel: Householder QR of the block below
+//                    the band (k_panel_qr, one launch per column, the panel streamed through LDS), then the
+//                    two-sided update  A22 <- Q^T A22 Q = A22 - V W^T - W V^T  in which all O(n^2 b) work is f64-MFMA
+//                    GEMM: X = A22 V (two triangular-operand GEMMs on the lower-stored A22), V^T [X|V] (Gram, split-K),
+//                    W = [X|V] [T; -S/2] and the SYR2K  [V|W] [W|V]^T.
+//   stage 2  sb2st   band -> tridiagonal by Householder bulge chasing (Lang's algorithm: sweep s annihilates column s
+//                    below the first sub-diagonal and chases the bulge down the band, one reflector of length <= 64
+//                    per block).  Task (s, k) only conflicts with (s+1, k-1) and later, so launch t runs every task
+//                    with 2 s + k = t, one workgroup each (k_bulge_step): 2 n + n/64 launches, no spin-waits.
+//   back-transformation  Z <- Q1 Q2 Z.  Q2: the reflectors of 64 consecutive sweeps at the same chase position form
+//                    a "diamond" (127 x 64 parallelogram) = one compact-WY block I - V T V^T; diamonds (S, k) are
+//                    applied in wavefronts 3 (Smax - S) + k = const as two grouped GEMMs per wavefront (bt2).
+//                    Q1: the stage-1 reflectors through the block back-transformation of backtransform.hip.
+//
+// Role in the reference: part of np.linalg.eigh (LAPACK dsyevd) at nma.py:61; LAPACK itself uses the one-stage dsytrd.
+#include <algorithm>
+#include <vector>
+
+#include "eigh_internal.h"
+
+namespace {
+
+constexpr int kB = 64;            // band half-width = panel width = reflector length of stage 2
+constexpr int kG = 64;            // sweeps per diamond
+constexpr int kLdab = 2 * kB;     // rows of the band storage: AB(i, j) = ab[(i - j) + j * kLdab]
+constexpr int kDiaLd = 128;       // leading dimension of a diamond (kB + kG - 1 = 127 rows used)
+constexpr int kDiaSize = kDiaLd * kG;
+constexpr int kQrRows = 128;      // rows of the panel one k_panel_qr workgroup owns
+constexpr int kSmallSplit = 8;    // split-K of the V^T [X1|X2|V] product
+
+struct HH {
+  double beta, tau, scale;
+};
+
+// LAPACK dlarfg scalars: x = (alpha, tail), xn2 = ||tail||^2;  H x = beta e1,  v = (1, scale * tail)
+__device__ __forceinline__ HH householder(double alpha, double xn2) {
+  HH h;
+  if (xn2 == 0.0) {
+    h.beta = alpha; h.tau = 0.0; h.scale = 0.0;
+    return h;
+  }
+  h.beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+  h.tau = (h.beta - alpha) / h.beta;
+  h.scale = 1.0 / (alpha - h.beta);
+  return h;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ================================================================================================================
+// Stage 1: panel QR.  Panel = A[r0 : n, j0 : j0 + kB] (m x kB, column-major, ld n).  Launch j (0 .. nr):
+//   (a) j >= 1: finish reflector j-1 from the partial results of launch j-1 (tail Gram row, pivot row) and apply it
+//       to columns j .. kB-1; column j-1 becomes (R entries above, beta at the pivot, v below); v also goes, with its
+//       explicit 1 and zeros above, into the three panel buffers [V|W], [W|V], [X1|X2|V];
+//   (b) j < nr: tail Gram row of column j:  g[c] = sum_{r > j} P[r, j] P[r, c]  (per 128-row chunk; chunk 0 also saves
+//       the pivot row P[j, j..]) for launch j+1.
+// Grid (chunks, batch), 256 threads; the chunk's columns j-1 .. kB-1 live in LDS for the duration of the launch.
+__global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, long long stride_a,
+                                                  double* __restrict__ tri_all, TriLayout TL,
+                                                  double* __restrict__ sb_all, SbLayout SL, int j0, int j, int nr) {
+  constexpr int LD = kQrRows + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* P = sm;                      // [kB][LD]   P[c * LD + r]
+  double* wv = sm + kB * LD;           // [kB]  w_c of the reflector being applied
+  double* vv = wv + kB;                // [kQrRows]  v_r
+  double* red = vv + kQrRows;          // [4][kB]
+  __shared__ double s_scale, s_beta, s_tau;
+
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const int chunk = blockIdx.x, nchunks = gridDim.x;
+  const int row_base = chunk * kQrRows;   // local (panel) row of this chunk's first row
+  const int tid = threadIdx.x;
+  const int prev = j - 1;
+  const int c_lo = j > 0 ? j - 1 : 0;
+  // launch j reads what launch j-1 left and writes for launch j+1 while other workgroups may still be reading:
+  // two copies, alternating
+  const int nchunk_cap = (n + kQrRows - 1) / kQrRows + 1;
+  const double* part_in = sb + SL.qrpart + (size_t)((j + 1) & 1) * nchunk_cap * kB;
+  double* part_out = sb + SL.qrpart + (size_t)(j & 1) * nchunk_cap * kB;
+  const double* piv_in = sb + SL.qrpiv + (size_t)((j + 1) & 1) * (kB + 8);
+  double* piv_out = sb + SL.qrpiv + (size_t)(j & 1) * (kB + 8);
+
+  // (a0) reflector scalars and w
+  if (j >= 1) {
+    if (tid < kB) {
+      double g = 0.0;
+      if (tid >= prev)
+        for (int ch = 0; ch < nchunks; ++ch) g += part_in[(size_t)ch * kB + tid];
+      red[tid] = g;   // tail Gram row of column prev
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double alpha = piv_in[prev];
+      const HH h = householder(alpha, red[prev]);
+      s_scale = h.scale; s_beta = h.beta; s_tau = h.tau;
+      if (chunk == 0) tri[TL.tau + j0 + prev] = h.tau;
+    }
+    __syncthreads();
+    if (tid < kB && tid >= j) {
+      const double prow = piv_in[tid];
+      wv[tid] = s_tau * (prow + s_scale * red[tid]);
+    }
+  }
+
+  // (1) chunk -> LDS: lanes along the rows (contiguous in memory)
+  {
+    const int r = tid & (kQrRows - 1), half = tid >> 7;
+    const int rl = row_base + r;
+    for (int c = c_lo + half; c < kB; c += 2)
+      P[c * LD + r] = rl < m ? A[(size_t)(j0 + c) * n + r0 + rl] : 0.0;
+  }
+  __syncthreads();
+
+  const int c = tid & 63, q = tid >> 6;   // column / row quarter (32 rows) of this thread in the compute phases
+  if (j >= 1) {
+    // (a1) v
+    if (tid < kQrRows) {
+      const int rl = row_base + tid;
+      double v = 0.0;
+      if (rl < m) v = rl > prev ? s_scale * P[prev * LD + tid] : (rl == prev ? 1.0 : 0.0);
+      vv[tid] = v;
+    }
+    __syncthreads();
+    // (a2) P[:, c] -= v w_c
+    if (c >= j) {
+      const double w = wv[c];
+#pragma unroll 8
+      for (int r = q * 32; r < q * 32 + 32; ++r) P[c * LD + r] -= vv[r] * w;
+    }
+    // column prev: v below the pivot, beta at it (rows above keep their R entries); and the panel buffers
+    if (tid < kQrRows) {
+      const int rl = row_base + tid;
+      if (rl < m) {
+        const double v = vv[tid];
+        if (rl > prev) P[prev * LD + tid] = v;
+        else if (rl == prev) P[prev * LD + tid] = s_beta;
+        const size_t row = (size_t)r0 + rl;
+        sb[SL.vw + (size_t)prev * n + row] = v;
+        sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
+        sb[SL.xv + (size_t)(2 * kB + prev) * n + row] = v;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (j < nr) {
+    // (b) tail Gram row of column j over this chunk: rows with local index > j
+    double acc = 0.0;
+    if (c >= j) {
+#pragma unroll 8
+      for (int r = q * 32; r < q * 32 + 32; ++r) {
+        const int rl = row_base + r;
+        if (rl > j && rl < m) acc += P[j * LD + r] * P[c * LD + r];
+      }
+    }
+    red[q * kB + c] = acc;
+    __syncthreads();
+    if (tid < kB) {
+      part_out[(size_t)chunk * kB + tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
+      if (chunk == 0 && tid >= j) piv_out[tid] = P[tid * LD + j];   // pivot row (alpha at [j])
+    }
+  } else {
+    // last launch of the panel: columns without a reflector (short last panel) are zero in the V buffers
+    for (int cc = nr; cc < kB; ++cc)
+      for (int r = tid; r < kQrRows; r += 256) {
+        const int rl = row_base + r;
+        if (rl < m) {
+          const size_t row = (size_t)r0 + rl;
+          sb[SL.vw + (size_t)cc * n + row] = 0.0;
+          sb[SL.wv + (size_t)(kB + cc) * n + row] = 0.0;
+          sb[SL.xv + (size_t)(2 * kB + cc) * n + row] = 0.0;
+        }
+      }
+  }
+
+  // (2) LDS -> chunk
+  if (j >= 1) {
+    const int r = tid & (kQrRows - 1), half = tid >> 7;
+    const int rl = row_base + r;
+    if (rl < m)
+      for (int cc = c_lo + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
+  }
+}
+
+// One workgroup per matrix: T (larft, forward columnwise) from tau and G = V^T V;  S = T^T (V^T X) T;
+// C = [T; T; -S/2]  (3 kB x kB, column-major), the right-hand factor of  W = [X1 | X2 | V] C.
+__global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri_all, TriLayout TL,
+                                                  double* __restrict__ sb_all, SbLayout SL, int j0) {
+  constexpr int LD = kB + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* G = sm;                 // [kB][LD]  G[i * LD + j]
+  double* M1 = G + kB * LD;
+  double* T = M1 + kB * LD;
+  double* U = T + kB * LD;
+  const double* tri = tri_all + (size_t)blockIdx.x * TL.slab;
+  double* sb = sb_all + (size_t)blockIdx.x * SL.slab;
+  const int tid = threadIdx.x;
+  // the split-K product is (kB x 3 kB), column-major ld kB: columns [X1 | X2 | V]
+  const double* prod = sb + SL.small;
+  const size_t slice = (size_t)kB * 3 * kB;
+  for (int idx = tid; idx < kB * kB; idx += 256) {
+    const int i = idx & 63, jj = idx >> 6;
+    double g = 0.0, x = 0.0;
+    for (int s = 0; s < kSmallSplit; ++s) {
+      const double* ps = prod + s * slice;
+      x += ps[i + (size_t)jj * kB] + ps[i + (size_t)(kB + jj) * kB];
+      g += ps[i + (size_t)(2 * kB + jj) * kB];
+    }
+    G[i * LD + jj] = g;
+    M1[i * LD + jj] = x;
+    T[i * LD + jj] = 0.0;
+  }
+  __syncthreads();
+  for (int qq = 0; qq < kB; ++qq) {
+    const double tau = tri[TL.tau + j0 + qq];
+    double s = 0.0;
+    if (tid < qq)
+      for (int l = tid; l < qq; ++l) s += T[tid * LD + l] * G[l * LD + qq];
+    __syncthreads();
+    if (tid < qq) T[tid * LD + qq] = -tau * s;
+    if (tid == qq) T[qq * LD + qq] = tau;
+    __syncthreads();
+  }
+  // U = M1 T ; S = T^T U
+  for (int idx = tid; idx < kB * kB; idx += 256) {
+    const int i = idx >> 6, jj = idx & 63;
+    double s = 0.0;
+    for (int l = 0; l <= jj; ++l) s += M1[i * LD + l] * T[l * LD + jj];
+    U[i * LD + jj] = s;
+  }
+  __syncthreads();
+  double* cm = sb + SL.cmat;   // ld 3 kB
+  for (int idx = tid; idx < kB * kB; idx += 256) {
+    const int i = idx & 63, jj = idx >> 6;
+    double s = 0.0;
+    for (int l = 0; l <= i; ++l) s += T[l * LD + i] * U[l * LD + jj];
+    const double t = T[i * LD + jj];
+    cm[i + (size_t)jj * 3 * kB] = t;
+    cm[kB + i + (size_t)jj * 3 * kB] = t;
+    cm[2 * kB + i + (size_t)jj * 3 * kB] = -0.5 * s;
+  }
+}
+
+// ================================================================================================================
+// Band storage and stage 2
+__global__ __launch_bounds__(256) void k_band_extract(const double* __restrict__ a_all, long long stride_a,
+                                                      double* __restrict__ sb_all, SbLayout SL) {
+  const int n = SL.n;
+  const double* A = a_all + (size_t)blockIdx.y * stride_a;
+  double* ab = sb_all + (size_t)blockIdx.y * SL.slab + SL.ab;
+  const size_t total = (size_t)kLdab * n;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int d = (int)(idx % kLdab), jj = (int)(idx / kLdab);
+    ab[idx] = (d <= kB && jj + d < n) ? A[(size_t)jj * n + jj + d] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_band_to_tri(const double* __restrict__ sb_all, SbLayout SL,
+                                                     double* __restrict__ tri_all, TriLayout TL) {
+  const int n = SL.n;
+  const double* ab = sb_all + (size_t)blockIdx.y * SL.slab + SL.ab;
+  double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    tri[TL.d + i] = ab[(size_t)i * kLdab];
+    tri[TL.e + i] = i < n - 1 ? ab[(size_t)i * kLdab + 1] : 0.0;
+  }
+}
+
+// After the band has been copied out: make the stage-1 reflectors a plain sub-matrix view of A for the block
+// back-transformation (unit entry at row c + kB, zeros between the diagonal block and the unit entry).
+__global__ __launch_bounds__(256) void k_sb_clean(double* __restrict__ a_all, long long stride_a, int n) {
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  const int c = blockIdx.x;   // column
+  for (int r = c + 1 + threadIdx.x; r <= std::min(c + kB, n - 1); r += 256) A[(size_t)c * n + r] = r == c + kB ? 1.0 : 0.0;
+}
+
+// Number of chase positions of sweep s: blocks of kB rows from row s+1 to n-1
+__host__ __device__ inline int chase_len(int n, int s) { return (n - 1 - s + kB - 1) / kB; }
+
+// Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
+__global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
+                                                    const int* __restrict__ dia_off, int t) {
+  constexpr int LD = kB + 1;
+  __shared__ double E[kB * LD];
+  __shared__ double D[kB * LD];
+  __shared__ double vp[kB], vn[kB], u[kB], red[4 * kB];
+  __shared__ double s_tau, s_beta, s_alpha2;
+
+  const int n = SL.n;
+  const int k = (t & 1) + 2 * (int)blockIdx.x;
+  const int s = (t - k) / 2;
+  if (s < 0 || s > n - 3 || k >= chase_len(n, s)) return;
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  double* ab = sb + SL.ab;
+  const int S = s / kG, cc = s - S * kG;
+  const size_t dia = (size_t)dia_off[S] + k;
+  double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kDiaLd + cc;   // this reflector's slot
+  const int tid = threadIdx.x;
+  const int i = tid & 63, q = tid >> 6;
+
+  const int r0 = s + 1 + k * kB;             // first row of the reflector being generated
+  const int L = std::min(kB, n - r0);        // its length (>= 1)
+
+  if (k > 0) {
+    const int c0 = r0 - kB;
+    const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kDiaLd + cc;
+    const double tau_p = sb[SL.tau2 + (dia - 1) * kG + cc];
+    if (tid < kB) vp[tid] = vdp[tid];
+    // E(i, j) = AB(r0 + i, c0 + j), rows i < L
+    for (int jj = q * 16; jj < q * 16 + 16; ++jj)
+      E[i * LD + jj] = i < L ? ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] : 0.0;
+    __syncthreads();
+    // u = E vp
+    {
+      double a = 0.0;
+#pragma unroll
+      for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += E[i * LD + jj] * vp[jj];
+      red[q * kB + i] = a;
+    }
+    __syncthreads();
+    if (tid < kB) u[tid] = tau_p * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
+    __syncthreads();
+#pragma unroll
+    for (int jj = q * 16; jj < q * 16 + 16; ++jj) E[i * LD + jj] -= u[i] * vp[jj];
+    __syncthreads();
+    // new reflector from the first column of E
+    if (tid < 64) {
+      const double x = E[tid * LD];
+      const double t2 = wave_sum((tid >= 1 && tid < L) ? x * x : 0.0);
+      const HH h = householder(E[0], t2);
+      vn[tid] = tid == 0 ? 1.0 : (tid < L ? x * h.scale : 0.0);
+      if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
+    }
+    __syncthreads();
+    // z_j = sum_i E[i, j] v_i  (j >= 1);  thread (j = i, rows q*16..)
+    {
+      double a = 0.0;
+#pragma unroll
+      for (int ii = q * 16; ii < q * 16 + 16; ++ii) a += E[ii * LD + i] * vn[ii];
+      red[q * kB + i] = a;
+    }
+    __syncthreads();
+    if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
+    __syncthreads();
+    // E <- H E, first column = beta e1; write back
+    for (int jj = q * 16; jj < q * 16 + 16; ++jj) {
+      double e = E[i * LD + jj] - vn[i] * u[jj];
+      if (jj == 0) e = i == 0 ? s_beta : 0.0;
+      if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
+    }
+  } else {
+    // sweep start: x = AB(s+1 .. s+L, s)
+    if (tid < 64) {
+      const double x = tid < L ? ab[(size_t)(1 + tid) + (size_t)s * kLdab] : 0.0;
+      const double t2 = wave_sum(tid >= 1 ? x * x : 0.0);
+      const double alpha = __shfl(x, 0);
+      const HH h = householder(alpha, t2);
+      vn[tid] = tid == 0 ? 1.0 : x * h.scale;
+      if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
+      if (tid < L) ab[(size_t)(1 + tid) + (size_t)s * kLdab] = tid == 0 ? h.beta : 0.0;
+    }
+    __syncthreads();
+  }
+
+  // two-sided update of the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored)
+  for (int jj = q * 16; jj < q * 16 + 16; ++jj) {
+    if (i >= jj) {
+      const double x = (i < L) ? ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] : 0.0;
+      D[i * LD + jj] = x;
+      D[jj * LD + i] = x;
+    }
+  }
+  __syncthreads();
+  {
+    double a = 0.0;
+#pragma unroll
+    for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += D[i * LD + jj] * vn[jj];
+    red[q * kB + i] = a;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double p = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
+    const double dot = wave_sum(p * vn[tid]);
+    const double alpha2 = -0.5 * s_tau * dot;
+    u[tid] = p + alpha2 * vn[tid];   // w
+  }
+  __syncthreads();
+  for (int jj = q * 16; jj < q * 16 + 16; ++jj)
+    if (i >= jj && i < L)
+      ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
+
+  // the reflector goes into its diamond
+  if (tid < L) vd[tid] = vn[tid];
+  if (tid == 0) sb[SL.tau2 + dia * kG + cc] = s_tau;
+  (void)s_alpha2;
+}
+
+// ================================================================================================================
+// Diamonds: T factor and V T.  One workgroup per (diamond, matrix).
+__global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all, SbLayout SL, int dia0) {
+  constexpr int LDV = kDiaLd + 1, LD = kG + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* V = sm;                    // [kG][LDV]  V[c * LDV + r]
+  double* G = V + kG * LDV;          // [kG][LD]
+  double* T = G + kG * LD;           // [kG][LD]
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const size_t dia = (size_t)dia0 + blockIdx.x;
+  const double* vd = sb + SL.vd + dia * kDiaSize;
+  const double* tau = sb + SL.tau2 + dia * kG;
+  const int tid = threadIdx.x;
+  {
+    const int r = tid & 127, half = tid >> 7;
+    for (int c = half; c < kG; c += 2) V[c * LDV + r] = vd[(size_t)c * kDiaLd + r];
+  }
+  for (int idx = tid; idx < kG * LD; idx += 256) T[idx] = 0.0;
+  __syncthreads();
+  // G[a, b] = v_a . v_b for a < b (column a is non-zero in rows a .. a+kB-1)
+  {
+    const int a = tid & 63, q = tid >> 6;
+    for (int b = q * 16; b < q * 16 + 16; ++b) {
+      double s = 0.0;
+      if (a < b) {
+        // overlap of the supports: rows b .. a + kB - 1
+        for (int r = b; r < a + kB; ++r) s += V[a * LDV + r] * V[b * LDV + r];
+      }
+      G[a * LD + b] = s;
+    }
+  }
+  __syncthreads();
+  for (int qq = 0; qq < kG; ++qq) {
+    const double tq = tau[qq];
+    double s = 0.0;
+    if (tid < qq)
+      for (int l = tid; l < qq; ++l) s += T[tid * LD + l] * G[l * LD + qq];
+    __syncthreads();
+    if (tid < qq) T[tid * LD + qq] = -tq * s;
+    if (tid == qq) T[qq * LD + qq] = tq;
+    __syncthreads();
+  }
+  // VT = V T  (kDiaLd x kG)
+  double* vt = sb + SL.vt2 + dia * kDiaSize;
+  {
+    const int r = tid & 127, half = tid >> 7;
+    for (int c = half * 32; c < half * 32 + 32; ++c) {
+      double s = 0.0;
+      // V[r, l] is non-zero for l <= r <= l + kB - 1, T[l, c] for l <= c
+      const int l0 = std::max(0, r - (kB - 1)), l1 = std::min(c, r);
+      for (int l = l0; l <= l1; ++l) s += V[l * LDV + r] * T[l * LD + c];
+      vt[(size_t)c * kDiaLd + r] = s;
+    }
+  }
+}
+
+}  // namespace
+
+// ================================================================================================================
+// Layout
+size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
+  SbLayout L{};
+  L.n = n;
+  long long off = 0;
+  auto take = [&](long long cnt) { long long o = off; off += (cnt + 31) / 32 * 32; return o; };
+  const int nchunk = (n + kQrRows - 1) / kQrRows + 1;
+  L.vw = take((long long)n * 2 * kB);
+  L.wv = take((long long)n * 2 * kB);
+  L.xv = take((long long)n * 3 * kB);
+  L.qrpart = take((long long)2 * nchunk * kB);
+  L.qrpiv = take(2 * (kB + 8));
+  L.small = take((long long)kSmallSplit * kB * 3 * kB);
+  L.cmat = take(3 * kB * kB);
+  L.ab = take((long long)kLdab * n);
+  // diamonds
+  const int nsweep = std::max(n - 2, 0);
+  L.ngroups = (nsweep + kG - 1) / kG;
+  long long ndia = 0;
+  int maxlen = 0;
+  for (int S = 0; S < L.ngroups; ++S) {
+    const int len = (n - 1 - S * kG + kB - 1) / kB;
+    ndia += len;
+    maxlen = std::max(maxlen, len);
+  }
+  L.ndia = ndia;
+  L.nslot = maxlen / 3 + 2;
+  L.vd = take(ndia * kDiaSize);
+  L.vt2 = take(ndia * kDiaSize);
+  L.tau2 = take(ndia * kG);
+  L.w1 = take((long long)L.nslot * kG * std::max(ncols, 1));
+  L.slab = off;
+  if (out) *out = L;
+  return (size_t)off;
+}
+
+int sb_desc_count(int n, int batch) {
+  const int npanels = n / kB + 1;
+  return npanels * 6 * batch;
+}
+
+long long sb_bt2_desc_count(int n, int batch) {
+  SbLayout L;
+  sb_slab_doubles(n, 1, &L);
+  return 2 * L.ndia * batch;
+}
+
+// Diamond offsets per sweep group (shared by all matrices of the batch): host copy, (ngroups + 1) ints.
+static std::vector<int> dia_offsets(int n) {
+  const int nsweep = std::max(n - 2, 0);
+  const int ng = (nsweep + kG - 1) / kG;
+  std::vector<int> off((size_t)ng + 1, 0);
+  for (int S = 0; S < ng; ++S) off[(size_t)S + 1] = off[(size_t)S] + (n - 1 - S * kG + kB - 1) / kB;
+  return off;
+}
+
+// ================================================================================================================
+// Stage 1 + 2 driver.  d_a: lower triangle valid (after mirror_lower_batched).  On exit: tri slab holds d, e and the
+// stage-1 tau; A holds the stage-1 reflectors (cleaned for the back-transformation); the sb slab holds the diamonds.
+int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_tri_ws,
+                         const TriLayout& TL, double* d_sb_ws, const SbLayout& SL, int* d_dia_off,
+                         GemmDesc* d_descs, float* ms_stage1, float* ms_stage2, double* d_band_copy) {
+  hipStream_t st = ctx->stream;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  const bool prof = ctx->profiling && ms_stage1 && ms_stage2;
+  if (prof) {
+    for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
+    SC_HIP(ctx, hipEventRecord(ev[0], st));
+  }
+
+  // ---- descriptors of stage 1: per panel [symm x 2 | vtx | w x 2 | syr2k] x batch
+  int npanels = 0;
+  while (n - (npanels + 1) * kB >= 2) ++npanels;
+  std::vector<GemmDesc> h((size_t)npanels * 6 * batch);
+  for (int p = 0; p < npanels; ++p) {
+    const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
+    for (int b = 0; b < batch; ++b) {
+      double* A = d_a + (size_t)b * stride_a;
+      double* sb = d_sb_ws + (size_t)b * SL.slab;
+      double* a22 = A + (size_t)r0 * n + r0;
+      GemmDesc* g = &h[((size_t)p * batch + b) * 6];
+      // X1 = L V
+      GemmDesc X1{};
+      X1.a = a22; X1.sa_i = 1; X1.sa_k = n; X1.a_tri = 1;
+      X1.b = sb + SL.xv + (size_t)2 * kB * n + r0; X1.sb_k = 1; X1.sb_j = n;
+      X1.c = sb + SL.xv + r0; X1.ldc = n;
+      X1.m = m; X1.n = kB; X1.k = m; X1.alpha = 1.0; X1.beta = 0.0;
+      g[0] = X1;
+      // X2 = strict(L)^T V
+      GemmDesc X2 = X1;
+      X2.sa_i = n; X2.sa_k = 1; X2.a_tri = 2;
+      X2.c = sb + SL.xv + (size_t)kB * n + r0;
+      g[1] = X2;
+      // V^T [X1 | X2 | V], split-K slices
+      GemmDesc P{};
+      P.a = sb + SL.xv + (size_t)2 * kB * n + r0; P.sa_i = n; P.sa_k = 1;
+      P.b = sb + SL.xv + r0; P.sb_k = 1; P.sb_j = n;
+      P.c = sb + SL.small; P.ldc = kB;
+      P.m = kB; P.n = 3 * kB; P.k = m; P.alpha = 1.0; P.beta = 0.0;
+      P.split_stride = (long long)kB * 3 * kB;
+      g[2] = P;
+      // W = [X1 | X2 | V] C  -> [V|W] second half and [W|V] first half
+      GemmDesc W{};
+      W.a = sb + SL.xv + r0; W.sa_i = 1; W.sa_k = n;
+      W.b = sb + SL.cmat; W.sb_k = 1; W.sb_j = 3 * kB;
+      W.c = sb + SL.vw + (size_t)kB * n + r0; W.ldc = n;
+      W.m = m; W.n = kB; W.k = 3 * kB; W.alpha = 1.0; W.beta = 0.0;
+      g[3] = W;
+      W.c = sb + SL.wv + r0;
+      g[4] = W;
+      // A22 -= [V|W] [W|V]^T, lower triangle
+      GemmDesc R{};
+      R.a = sb + SL.vw + r0; R.sa_i = 1; R.sa_k = n;
+      R.b = sb + SL.wv + r0; R.sb_k = n; R.sb_j = 1;
+      R.c = a22; R.ldc = n;
+      R.m = m; R.n = m; R.k = 2 * kB; R.alpha = -1.0; R.beta = 1.0;
+      R.lower_only = 1;
+      g[5] = R;
+    }
+  }
+  // regroup so that each launch's records are contiguous: [panel][kind][batch]
+  std::vector<GemmDesc> hs(h.size());
+  for (int p = 0; p < npanels; ++p)
+    for (int b = 0; b < batch; ++b) {
+      const GemmDesc* g = &h[((size_t)p * batch + b) * 6];
+      GemmDesc* o = &hs[(size_t)p * 6 * batch];
+      o[0 * batch + b] = g[0];              // symm: 2 * batch records: [X1 x batch | X2 x batch]
+      o[1 * batch + b] = g[1];
+      o[2 * batch + b] = g[2];
+      o[3 * batch + b] = g[3];              // w: 2 * batch records
+      o[4 * batch + b] = g[4];
+      o[5 * batch + b] = g[5];
+    }
+  if (!hs.empty())
+    SC_HIP(ctx, hipMemcpyAsync(d_descs, hs.data(), hs.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  const std::vector<int> doff = dia_offsets(n);
+  SC_HIP(ctx, hipMemcpyAsync(d_dia_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice, st));
+
+  // tau of columns without a reflector must read 0
+  for (int b = 0; b < batch; ++b)
+    SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * TL.slab + TL.tau, 0, sizeof(double) * n, st));
+
+  const size_t lds_qr = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kB + kQrRows + 4 * kB);
+  const size_t lds_small = sizeof(double) * 4 * kB * (kB + 1);
+  for (int p = 0; p < npanels; ++p) {
+    const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
+    const int nr = std::min(kB, m - 1);
+    const int nchunks = (m + kQrRows - 1) / kQrRows;
+    for (int j = 0; j <= nr; ++j)
+      hipLaunchKernelGGL(k_panel_qr, dim3((unsigned)nchunks, (unsigned)batch), dim3(256), lds_qr, st, d_a, stride_a,
+                         d_tri_ws, TL, d_sb_ws, SL, j0, j, nr);
+    const GemmDesc* g = d_descs + (size_t)p * 6 * batch;
+    SC_TRY(launch_gemm_f64(ctx, g, 2 * batch, m, kB, kGemmTile, 1, false, true));
+    SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit));
+    hipLaunchKernelGGL(k_sb_small, dim3((unsigned)batch), dim3(256), lds_small, st, d_tri_ws, TL, d_sb_ws, SL, j0);
+    SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile));
+    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile));
+  }
+  SC_HIP(ctx, hipGetLastError());
+  if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
+
+  // ---- stage 2
+  hipLaunchKernelGGL(k_band_extract, dim3(256, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, d_sb_ws, SL);
+  if (d_band_copy)   // debugging aid: the band as stage 1 left it (first matrix)
+    SC_HIP(ctx, hipMemcpyAsync(d_band_copy, d_sb_ws + SL.ab, sizeof(double) * kLdab * n, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_sb_clean, dim3((unsigned)n, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n);
+  for (int b = 0; b < batch; ++b) {
+    double* sb = d_sb_ws + (size_t)b * SL.slab;
+    SC_HIP(ctx, hipMemsetAsync(sb + SL.vd, 0, sizeof(double) * (size_t)SL.ndia * kDiaSize, st));
+    SC_HIP(ctx, hipMemsetAsync(sb + SL.tau2, 0, sizeof(double) * (size_t)SL.ndia * kG, st));
+  }
+  if (n >= 3) {
+    const int t_max = 2 * (n - 3) + chase_len(n, n - 3) - 1;
+    const int gx = chase_len(n, 0) / 2 + 1;
+    for (int t = 0; t <= t_max; ++t)
+      hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off, t);
+  }
+  hipLaunchKernelGGL(k_band_to_tri, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL,
+                     d_tri_ws, TL);
+  SC_HIP(ctx, hipGetLastError());
+  if (prof) {
+    SC_HIP(ctx, hipEventRecord(ev[2], st));
+    SC_HIP(ctx, hipEventSynchronize(ev[2]));
+    SC_HIP(ctx, hipEventElapsedTime(ms_stage1, ev[0], ev[1]));
+    SC_HIP(ctx, hipEventElapsedTime(ms_stage2, ev[1], ev[2]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  SC_HIP(ctx, hipStreamSynchronize(st));   // host descriptor vectors must outlive their uploads
+  return SC_OK;
+}
+
+// ================================================================================================================
+// Z <- Q2 Z: diamonds in wavefronts.  d_z: (batch) ncols columns of length n (ld n).
+int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, double* d_z, long long stride_z,
+                int ncols, GemmDesc* d_descs) {
+  hipStream_t st = ctx->stream;
+  if (n < 3 || SL.ndia == 0) return SC_OK;
+  const std::vector<int> doff = dia_offsets(n);
+  const int ng = SL.ngroups;
+
+  // T factors and V T of all diamonds
+  {
+    const size_t lds = sizeof(double) * ((size_t)kG * (kDiaLd + 1) + 2 * kG * (kG + 1));
+    for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
+      const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
+      hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), lds, st, d_sb_ws, SL, (int)d0);
+    }
+    SC_HIP(ctx, hipGetLastError());
+  }
+
+  // wavefront tau = 3 (ng - 1 - S) + k
+  struct Step { size_t first; int count; int max_rows; };
+  std::vector<Step> steps;
+  std::vector<GemmDesc> h;
+  h.reserve((size_t)2 * SL.ndia * batch);
+  int tmax = 0;
+  for (int S = 0; S < ng; ++S) tmax = std::max(tmax, 3 * (ng - 1 - S) + (doff[(size_t)S + 1] - doff[(size_t)S]) - 1);
+  for (int t = 0; t <= tmax; ++t) {
+    std::vector<std::pair<int, int>> act;   // (S, k)
+    for (int S = ng - 1; S >= 0; --S) {
+      const int k = t - 3 * (ng - 1 - S);
+      if (k < 0) break;
+      if (k < doff[(size_t)S + 1] - doff[(size_t)S]) act.emplace_back(S, k);
+    }
+    if (act.empty()) continue;
+    if ((int)act.size() > SL.nslot)
+      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "internal: %d concurrent diamonds, %d slots", (int)act.size(), SL.nslot);
+    Step stp{h.size(), (int)act.size() * batch, 0};
+    // W1 = VD^T Z[rows]  for all (slot, matrix), then the updates
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t a = 0; a < act.size(); ++a) {
+        const int S = act[a].first, k = act[a].second;
+        const size_t dia = (size_t)doff[(size_t)S] + k;
+        const int ro = S * kG + 1 + k * kB;
+        const int rows = std::min(kB + kG - 1, n - ro);
+        stp.max_rows = std::max(stp.max_rows, rows);
+        for (int b = 0; b < batch; ++b) {
+          double* sb = d_sb_ws + (size_t)b * SL.slab;
+          double* w1 = sb + SL.w1 + (size_t)a * kG * ncols;
+          double* z = d_z + (size_t)b * stride_z + ro;
+          GemmDesc D{};
+          if (pass == 0) {
+            D.a = sb + SL.vd + dia * kDiaSize; D.sa_i = kDiaLd; D.sa_k = 1;
+            D.b = z; D.sb_k = 1; D.sb_j = n;
+            D.c = w1; D.ldc = kG;
+            D.m = kG; D.n = ncols; D.k = rows; D.alpha = 1.0; D.beta = 0.0;
+          } else {
+            D.a = sb + SL.vt2 + dia * kDiaSize; D.sa_i = 1; D.sa_k = kDiaLd;
+            D.b = w1; D.sb_k = 1; D.sb_j = kG;
+            D.c = z; D.ldc = n;
+            D.m = rows; D.n = ncols; D.k = kG; D.alpha = -1.0; D.beta = 1.0;
+          }
+          h.push_back(D);
+        }
+      }
+    steps.push_back(stp);
+  }
+  SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  for (const Step& s : steps) {
+    SC_TRY(launch_gemm_f64(ctx, d_descs + s.first, s.count, kG, ncols, kGemmTile));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + s.first + s.count, s.count, s.max_rows, ncols, kGemmTile));
+  }
+  SC_HIP(ctx, hipGetLastError());
+  SC_HIP(ctx, hipStreamSynchronize(st));
+  return SC_OK;
+}
+
+int sb_band_width() { return kB; }
+
+// ---- debugging entry point (not part of the public C ABI): band after stage 1 (128 x n, AB(i,j) at [(i-j) + 128 j])
+// and the tridiagonal after stage 2 of ONE host matrix (NumPy layout, lower triangle read).
+extern "C" int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* band_out, double* d_out, double* e_out) {
+  if (!ctx || !a || n < 4 * kB) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  TriLayout TL{};
+  TL.n = n; TL.nb = kB;
+  TL.d = 0; TL.e = n; TL.tau = 2 * (long long)n; TL.slab = 3 * (long long)n + 64;
+  SbLayout SL;
+  const size_t sbd = sb_slab_doubles(n, 0, &SL);
+  double *d_a = nullptr, *d_tri = nullptr, *d_sb = nullptr, *d_band = nullptr;
+  int* d_off = nullptr;
+  GemmDesc* d_desc = nullptr;
+  SC_HIP(ctx, hipMalloc(&d_a, sizeof(double) * (size_t)n * n));
+  SC_HIP(ctx, hipMalloc(&d_tri, sizeof(double) * TL.slab));
+  SC_HIP(ctx, hipMalloc(&d_sb, sizeof(double) * sbd));
+  SC_HIP(ctx, hipMalloc(&d_band, sizeof(double) * kLdab * n));
+  SC_HIP(ctx, hipMalloc(&d_off, sizeof(int) * (n / 64 + 8)));
+  SC_HIP(ctx, hipMalloc(&d_desc, sizeof(GemmDesc) * sb_desc_count(n, 1)));
+  SC_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = mirror_lower_batched(ctx, d_a, (long long)n * n, n, 1);
+  if (rc == SC_OK)
+    rc = sytrd_2stage_batched(ctx, d_a, (long long)n * n, n, 1, d_tri, TL, d_sb, SL, d_off, d_desc, nullptr, nullptr,
+                              d_band);
+  if (rc == SC_OK) {
+    (void)hipMemcpy(band_out, d_band, sizeof(double) * kLdab * n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(d_out, d_tri + TL.d, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(e_out, d_tri + TL.e, sizeof(double) * n, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_a); (void)hipFree(d_tri); (void)hipFree(d_sb); (void)hipFree(d_band); (void)hipFree(d_off);
+  (void)hipFree(d_desc);
+  return rc;
+}
