@@ -114,11 +114,20 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   }
 
   // (1) chunk -> LDS: lanes along the rows (contiguous in memory)
+  // (loads are unconditional, with clamped indices, and issued eight at a time: a load that is merged with a zero
+  //  under a predicate makes hipcc wait for it before issuing the next one)
   {
     const int r = tid & (kQrRows - 1), half = tid >> 7;
     const int rl = row_base + r;
-    for (int c = c_lo + half; c < kB; c += 2)
-      P[c * LD + r] = rl < m ? A[(size_t)(j0 + c) * n + r0 + rl] : 0.0;
+    const double* src = A + (size_t)j0 * n + r0 + std::min(rl, m - 1);
+    for (int c = c_lo + half; c < kB; c += 16) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+    }
   }
   __syncthreads();
 
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
                                                     const int* __restrict__ dia_off, int t) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
-  __shared__ double D[kB * LD];
+  double* D = E;   // the diagonal block is processed after E has gone back to memory: same buffer
   __shared__ double vp[kB], vn[kB], u[kB], red[4 * kB];
   __shared__ double s_tau, s_beta, s_alpha2;
 
@@ -313,14 +322,33 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   const int r0 = s + 1 + k * kB;             // first row of the reflector being generated
   const int L = std::min(kB, n - r0);        // its length (>= 1)
 
+  // the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored) is not touched before its own update:
+  // fetch it right away (unconditional loads with clamped indices, masked when they go to LDS)
+  double d16[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int jc = std::min(q * 16 + u, L - 1);
+    const int ic = std::min(std::max(i, jc), L - 1);
+    d16[u] = ab[(size_t)(ic - jc) + (size_t)(r0 + jc) * kLdab];
+  }
+
   if (k > 0) {
     const int c0 = r0 - kB;
     const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kDiaLd + cc;
     const double tau_p = sb[SL.tau2 + (dia - 1) * kG + cc];
     if (tid < kB) vp[tid] = vdp[tid];
     // E(i, j) = AB(r0 + i, c0 + j), rows i < L
-    for (int jj = q * 16; jj < q * 16 + 16; ++jj)
-      E[i * LD + jj] = i < L ? ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] : 0.0;
+    {
+      double t16[16];
+      const int ic = std::min(i, L - 1);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int jj = q * 16 + u;
+        t16[u] = ab[(size_t)(kB + ic - jj) + (size_t)(c0 + jj) * kLdab];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) E[i * LD + q * 16 + u] = i < L ? t16[u] : 0.0;
+    }
     __syncthreads();
     // u = E vp
     {
@@ -360,10 +388,12 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       if (jj == 0) e = i == 0 ? s_beta : 0.0;
       if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
     }
+    __syncthreads();   // D reuses E's buffer
   } else {
     // sweep start: x = AB(s+1 .. s+L, s)
     if (tid < 64) {
-      const double x = tid < L ? ab[(size_t)(1 + tid) + (size_t)s * kLdab] : 0.0;
+      const double xr = ab[(size_t)(1 + std::min(tid, L - 1)) + (size_t)s * kLdab];
+      const double x = tid < L ? xr : 0.0;
       const double t2 = wave_sum(tid >= 1 ? x * x : 0.0);
       const double alpha = __shfl(x, 0);
       const HH h = householder(alpha, t2);
@@ -375,9 +405,11 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   }
 
   // two-sided update of the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored)
-  for (int jj = q * 16; jj < q * 16 + 16; ++jj) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int jj = q * 16 + u;
     if (i >= jj) {
-      const double x = (i < L) ? ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] : 0.0;
+      const double x = (i < L) ? d16[u] : 0.0;
       D[i * LD + jj] = x;
       D[jj * LD + i] = x;
     }
