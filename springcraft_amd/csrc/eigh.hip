@@ -88,7 +88,6 @@ Plan make_plan(int n, int batch, bool vectors) {
     P.off_sb = take(sb_slab_doubles(n, vectors ? n : 0, &P.SL) * 8 * batch);
     P.off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
     P.n_syr2k = std::max(P.n_syr2k, sb_desc_count(n, batch));
-    if (vectors) P.n_bt2 = sb_bt2_desc_count(n, batch);
   }
   if (vectors) {
     P.off_dc = take(dc_slab_doubles(n, &P.DL) * 8 * batch);
@@ -234,7 +233,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
     if (P.two)
-      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, d_v, stride_a, n, descs + P.n_syr2k + P.n_merge + P.n_bt));
+      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n));
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
                                  descs + P.n_syr2k + P.n_merge, P.two ? sb_band_width() : 1));
   }

@@ -105,14 +105,12 @@ struct SbLayout {
   int ngroups;        // sweep groups (64 sweeps each)
   long long ndia;     // diamonds
   int nslot;          // concurrently applied diamonds in the back-transformation
-  long long vd, vt2;  // diamonds V and V T: ndia x (128 x 64)
+  long long vd, vt2;  // diamonds: V row-major (128 rows x 64 sweeps), V T column-major (ld 128)
   long long tau2;     // ndia x 64
-  long long w1;       // nslot x 64 x ncols
 };
 // ncols: columns of Z the back-transformation will be applied to (0: eigenvalues only)
 size_t sb_slab_doubles(int n, int ncols, SbLayout* out);
 int sb_desc_count(int n, int batch);
-long long sb_bt2_desc_count(int n, int batch);
 int sb_band_width();
 // d_a: column-major lower triangle valid.  On exit d, e (and the stage-1 tau) are in the tri slab, the stage-1
 // reflectors in A (unit entry of column c at row c + sb_band_width()), the stage-2 reflectors in the sb slab.
@@ -121,8 +119,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                          GemmDesc* d_descs /* sb_desc_count */, float* ms_stage1, float* ms_stage2,
                          double* d_band_copy = nullptr);
 // Z <- Q2 Z (stage-2 reflectors)
-int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, double* d_z, long long stride_z,
-                int ncols, GemmDesc* d_descs /* sb_bt2_desc_count */);
+int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, const int* d_dia_off, double* d_z,
+                long long stride_z, int ncols);
 
 // ---- partial spectrum (stein.hip) -----------------------------------------------------------------------
 size_t stein_workspace_doubles(int n, int m);

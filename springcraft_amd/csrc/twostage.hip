@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   double* ab = sb + SL.ab;
   const int S = s / kG, cc = s - S * kG;
   const size_t dia = (size_t)dia_off[S] + k;
-  double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kDiaLd + cc;   // this reflector's slot
+  // diamonds are stored row-major (sweep index contiguous): element (row r, sweep c) at [c + r * kG]
+  double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kG + cc;   // this reflector's first entry (row cc, column cc)
   const int tid = threadIdx.x;
   const int i = tid & 63, q = tid >> 6;
 
@@ -334,9 +335,9 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 
   if (k > 0) {
     const int c0 = r0 - kB;
-    const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kDiaLd + cc;
+    const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kG + cc;
     const double tau_p = sb[SL.tau2 + (dia - 1) * kG + cc];
-    if (tid < kB) vp[tid] = vdp[tid];
+    if (tid < kB) vp[tid] = vdp[(size_t)tid * kG];
     // E(i, j) = AB(r0 + i, c0 + j), rows i < L
     {
       double t16[16];
@@ -434,40 +435,39 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
 
   // the reflector goes into its diamond
-  if (tid < L) vd[tid] = vn[tid];
+  if (tid < L) vd[(size_t)tid * kG] = vn[tid];
   if (tid == 0) sb[SL.tau2 + dia * kG + cc] = s_tau;
   (void)s_alpha2;
 }
 
 // ================================================================================================================
-// Diamonds: T factor and V T.  One workgroup per (diamond, matrix).
+// Diamonds: T factor and V T.  One workgroup per (diamond, matrix).  The diamond is held compactly in LDS
+// (Vc[c][i] = V[c + i, c], the 64 entries of reflector c), G and T share one buffer.
 __global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all, SbLayout SL, int dia0) {
-  constexpr int LDV = kDiaLd + 1, LD = kG + 1;
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* V = sm;                    // [kG][LDV]  V[c * LDV + r]
-  double* G = V + kG * LDV;          // [kG][LD]
-  double* T = G + kG * LD;           // [kG][LD]
+  constexpr int LD = kG + 1;
+  __shared__ double Vc[kG * LD];     // Vc[c * LD + i]
+  __shared__ double GT[kG * LD];     // G[a * LD + b] (a < b), overwritten column by column with T
   double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
   const size_t dia = (size_t)dia0 + blockIdx.x;
   const double* vd = sb + SL.vd + dia * kDiaSize;
   const double* tau = sb + SL.tau2 + dia * kG;
   const int tid = threadIdx.x;
   {
-    const int r = tid & 127, half = tid >> 7;
-    for (int c = half; c < kG; c += 2) V[c * LDV + r] = vd[(size_t)c * kDiaLd + r];
+    // row r of the diamond holds sweeps c in [r - 63, r]; lanes along c (contiguous in memory)
+    const int c = tid & 63, q = tid >> 6;
+    for (int i = q; i < kB; i += 4) Vc[c * LD + i] = vd[(size_t)(c + i) * kG + c];
   }
-  for (int idx = tid; idx < kG * LD; idx += 256) T[idx] = 0.0;
   __syncthreads();
-  // G[a, b] = v_a . v_b for a < b (column a is non-zero in rows a .. a+kB-1)
+  // G[a, b] = v_a . v_b for a < b: rows b .. a + 63, i.e. entries i = b - a .. 63 of v_a against 0 .. of v_b
   {
     const int a = tid & 63, q = tid >> 6;
     for (int b = q * 16; b < q * 16 + 16; ++b) {
       double s = 0.0;
       if (a < b) {
-        // overlap of the supports: rows b .. a + kB - 1
-        for (int r = b; r < a + kB; ++r) s += V[a * LDV + r] * V[b * LDV + r];
+        const int sh = b - a;
+        for (int i = sh; i < kB; ++i) s += Vc[a * LD + i] * Vc[b * LD + i - sh];
       }
-      G[a * LD + b] = s;
+      GT[a * LD + b] = s;
     }
   }
   __syncthreads();
@@ -475,23 +475,150 @@ __global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all
     const double tq = tau[qq];
     double s = 0.0;
     if (tid < qq)
-      for (int l = tid; l < qq; ++l) s += T[tid * LD + l] * G[l * LD + qq];
+      for (int l = tid; l < qq; ++l) s += GT[tid * LD + l] * GT[l * LD + qq];   // T[tid, l] (l < qq: already T) * G[l, qq]
     __syncthreads();
-    if (tid < qq) T[tid * LD + qq] = -tq * s;
-    if (tid == qq) T[qq * LD + qq] = tq;
+    if (tid < qq) GT[tid * LD + qq] = -tq * s;
+    if (tid == qq) GT[qq * LD + qq] = tq;
     __syncthreads();
   }
-  // VT = V T  (kDiaLd x kG)
+  // VT[r, c] = sum_l V[r, l] T[l, c]   (128 x 64, column-major ld 128); V[r, l] = Vc[l][r - l] for 0 <= r - l < 64
   double* vt = sb + SL.vt2 + dia * kDiaSize;
   {
     const int r = tid & 127, half = tid >> 7;
     for (int c = half * 32; c < half * 32 + 32; ++c) {
       double s = 0.0;
-      // V[r, l] is non-zero for l <= r <= l + kB - 1, T[l, c] for l <= c
       const int l0 = std::max(0, r - (kB - 1)), l1 = std::min(c, r);
-      for (int l = l0; l <= l1; ++l) s += V[l * LDV + r] * T[l * LD + c];
+      for (int l = l0; l <= l1; ++l) s += Vc[l * LD + r - l] * GT[l * LD + c];
       vt[(size_t)c * kDiaLd + r] = s;
     }
+  }
+}
+
+// ================================================================================================================
+// Z <- Q2 Z, fused.  The columns of Z are independent, so one workgroup takes kNc = 32 columns through ALL diamonds
+// (sweep groups last to first, chase positions first to last) with no synchronisation between workgroups:
+//   W1^T (32 x 64) = Z^T (32 x 128) VD (128 x 64)           A operand: LDS copy of the Z window, B: VD from L2
+//   Z^T (32 x 128) -= W1^T (32 x 64) VT^T (64 x 128)          A operand: W1 via LDS, B: VT from L2
+// The 128-row window of Z stays in registers as MFMA accumulators (wave w owns rows 16w.. of each 64-row half); going
+// from one chase position to the next, the lower half becomes the upper half (register rename), 64 finished rows are
+// stored and 64 new rows are loaded: Z is read once and written once per sweep group.
+constexpr int kNc = 32;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__ sb_all, SbLayout SL,
+                                                      const int* __restrict__ dia_off, double* __restrict__ z_all,
+                                                      long long stride_z, int ncols) {
+  constexpr int LDH = kB + 2;      // Z window copy: [col][row in half], 66: conflict-free A-operand reads
+  constexpr int LDW = kNc + 16;    // W1 copy: [sweep][col]
+  __shared__ double Zs[2][kNc * LDH];
+  __shared__ double W1s[kG * LDW];
+  const int n = SL.n;
+  const double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  double* Z = z_all + (size_t)blockIdx.y * stride_z;
+  const int j0 = blockIdx.x * kNc;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  // accumulators: zt[h][ni][r] <-> Z(row = win + 64 h + 16 w + fr, col = j0 + 16 ni + fk + 4 r)
+  d4 zt[2][2];
+  double b1[32], b2[2][16];
+
+  auto load_half = [&](int h, int row0) {   // rows row0 + 16 w + fr
+    const int row = row0 + 16 * w + fr;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = j0 + 16 * ni + fk + 4 * r;
+        // unconditional load from a clamped address, masked afterwards
+        const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
+        zt[h][ni][r] = (row < n && col < ncols) ? v : 0.0;
+      }
+  };
+  auto store_half = [&](int h, int row0) {
+    const int row = row0 + 16 * w + fr;
+    if (row >= n) return;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = j0 + 16 * ni + fk + 4 * r;
+        if (col < ncols) Z[(size_t)col * n + row] = zt[h][ni][r];
+      }
+  };
+  auto copy_half_to_lds = [&](int h, int phys) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Zs[phys][(16 * ni + fk + 4 * r) * LDH + 16 * w + fr] = zt[h][ni][r];
+  };
+  auto fetch_b1 = [&](size_t dia) {   // VD[row 4 kk + fk][sweep 16 w + fr]
+    const double* vd = sb + SL.vd + dia * kDiaSize + 16 * w + fr + (size_t)fk * kG;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) b1[kk] = vd[(size_t)kk * 4 * kG];
+  };
+  auto fetch_b2 = [&](size_t dia) {   // VT[row 64 h + 16 w + fr][sweep 4 kk + fk]
+    const double* vt = sb + SL.vt2 + dia * kDiaSize + 16 * w + fr + (size_t)fk * kDiaLd;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) b2[h][kk] = vt[(size_t)kk * 4 * kDiaLd + 64 * h];
+  };
+
+  for (int S = SL.ngroups - 1; S >= 0; --S) {
+    const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
+    int win = S * kG + 1;          // first row of the window
+    int par = 0;                   // physical LDS buffer of the window's first half
+    load_half(0, win);
+    load_half(1, win + 64);
+    fetch_b1((size_t)d0);
+    fetch_b2((size_t)d0);
+    copy_half_to_lds(0, 0);
+    copy_half_to_lds(1, 1);
+    for (int k = 0; k < nk; ++k) {
+      __syncthreads();   // window copy complete
+      // ---- W1^T = Z^T VD
+      d4 c1[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) {
+        const double* zs = Zs[(kk >> 4) ^ par];
+        const int rr = (kk & 15) * 4 + fk;
+        const double a0 = zs[fr * LDH + rr], a1 = zs[(16 + fr) * LDH + rr];
+        c1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1[kk], c1[0], 0, 0, 0);
+        c1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[kk], c1[1], 0, 0, 0);
+      }
+      if (k + 1 < nk) fetch_b1((size_t)d0 + k + 1);   // consumed: refill for the next diamond
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W1s[(16 * w + fr) * LDW + 16 * ni + fk + 4 * r] = -c1[ni][r];
+      __syncthreads();   // W1 complete; nobody reads the window copy any more
+      // ---- Z^T -= W1^T VT^T
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const double a0 = W1s[(4 * kk + fk) * LDW + fr], a1 = W1s[(4 * kk + fk) * LDW + 16 + fr];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          zt[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[h][kk], zt[h][0], 0, 0, 0);
+          zt[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[h][kk], zt[h][1], 0, 0, 0);
+        }
+      }
+      if (k + 1 < nk) fetch_b2((size_t)d0 + k + 1);
+      // ---- slide: the first half is finished
+      store_half(0, win);
+      if (k + 1 < nk) {
+        zt[0][0] = zt[1][0];
+        zt[0][1] = zt[1][1];
+        copy_half_to_lds(0, par ^ 1);       // the old second half (updated) stays where it is, as the new first half
+        win += 64;
+        load_half(1, win + 64);
+        copy_half_to_lds(1, par);           // new rows go where the finished half was
+        par ^= 1;
+      } else {
+        store_half(1, win + 64);
+      }
+    }
+    __syncthreads();   // the next group rewrites both window buffers
   }
 }
 
@@ -528,7 +655,7 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   L.vd = take(ndia * kDiaSize);
   L.vt2 = take(ndia * kDiaSize);
   L.tau2 = take(ndia * kG);
-  L.w1 = take((long long)L.nslot * kG * std::max(ncols, 1));
+  (void)ncols;
   L.slab = off;
   if (out) *out = L;
   return (size_t)off;
@@ -539,11 +666,6 @@ int sb_desc_count(int n, int batch) {
   return npanels * 6 * batch;
 }
 
-long long sb_bt2_desc_count(int n, int batch) {
-  SbLayout L;
-  sb_slab_doubles(n, 1, &L);
-  return 2 * L.ndia * batch;
-}
 
 // Diamond offsets per sweep group (shared by all matrices of the batch): host copy, (ngroups + 1) ints.
 static std::vector<int> dia_offsets(int n) {
@@ -690,78 +812,18 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
 }
 
 // ================================================================================================================
-// Z <- Q2 Z: diamonds in wavefronts.  d_z: (batch) ncols columns of length n (ld n).
-int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, double* d_z, long long stride_z,
-                int ncols, GemmDesc* d_descs) {
+// Z <- Q2 Z.  d_z: (batch) ncols columns of length n (ld n).  d_dia_off: the offsets uploaded by sytrd_2stage_batched.
+int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, const int* d_dia_off, double* d_z,
+                long long stride_z, int ncols) {
   hipStream_t st = ctx->stream;
-  if (n < 3 || SL.ndia == 0) return SC_OK;
-  const std::vector<int> doff = dia_offsets(n);
-  const int ng = SL.ngroups;
-
-  // T factors and V T of all diamonds
-  {
-    const size_t lds = sizeof(double) * ((size_t)kG * (kDiaLd + 1) + 2 * kG * (kG + 1));
-    for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
-      const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
-      hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), lds, st, d_sb_ws, SL, (int)d0);
-    }
-    SC_HIP(ctx, hipGetLastError());
+  if (n < 3 || SL.ndia == 0 || ncols <= 0) return SC_OK;
+  for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
+    const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
+    hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
   }
-
-  // wavefront tau = 3 (ng - 1 - S) + k
-  struct Step { size_t first; int count; int max_rows; };
-  std::vector<Step> steps;
-  std::vector<GemmDesc> h;
-  h.reserve((size_t)2 * SL.ndia * batch);
-  int tmax = 0;
-  for (int S = 0; S < ng; ++S) tmax = std::max(tmax, 3 * (ng - 1 - S) + (doff[(size_t)S + 1] - doff[(size_t)S]) - 1);
-  for (int t = 0; t <= tmax; ++t) {
-    std::vector<std::pair<int, int>> act;   // (S, k)
-    for (int S = ng - 1; S >= 0; --S) {
-      const int k = t - 3 * (ng - 1 - S);
-      if (k < 0) break;
-      if (k < doff[(size_t)S + 1] - doff[(size_t)S]) act.emplace_back(S, k);
-    }
-    if (act.empty()) continue;
-    if ((int)act.size() > SL.nslot)
-      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "internal: %d concurrent diamonds, %d slots", (int)act.size(), SL.nslot);
-    Step stp{h.size(), (int)act.size() * batch, 0};
-    // W1 = VD^T Z[rows]  for all (slot, matrix), then the updates
-    for (int pass = 0; pass < 2; ++pass)
-      for (size_t a = 0; a < act.size(); ++a) {
-        const int S = act[a].first, k = act[a].second;
-        const size_t dia = (size_t)doff[(size_t)S] + k;
-        const int ro = S * kG + 1 + k * kB;
-        const int rows = std::min(kB + kG - 1, n - ro);
-        stp.max_rows = std::max(stp.max_rows, rows);
-        for (int b = 0; b < batch; ++b) {
-          double* sb = d_sb_ws + (size_t)b * SL.slab;
-          double* w1 = sb + SL.w1 + (size_t)a * kG * ncols;
-          double* z = d_z + (size_t)b * stride_z + ro;
-          GemmDesc D{};
-          if (pass == 0) {
-            D.a = sb + SL.vd + dia * kDiaSize; D.sa_i = kDiaLd; D.sa_k = 1;
-            D.b = z; D.sb_k = 1; D.sb_j = n;
-            D.c = w1; D.ldc = kG;
-            D.m = kG; D.n = ncols; D.k = rows; D.alpha = 1.0; D.beta = 0.0;
-          } else {
-            D.a = sb + SL.vt2 + dia * kDiaSize; D.sa_i = 1; D.sa_k = kDiaLd;
-            D.b = w1; D.sb_k = 1; D.sb_j = kG;
-            D.c = z; D.ldc = n;
-            D.m = rows; D.n = ncols; D.k = kG; D.alpha = -1.0; D.beta = 1.0;
-          }
-          h.push_back(D);
-        }
-      }
-    steps.push_back(stp);
-  }
-  SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
-  for (const Step& s : steps) {
-    SC_TRY(launch_gemm_f64(ctx, d_descs + s.first, s.count, kG, ncols, kGemmTile));
-    SC_TRY(launch_gemm_f64(ctx, d_descs + s.first + s.count, s.count, s.max_rows, ncols, kGemmTile));
-  }
+  hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)((ncols + kNc - 1) / kNc), (unsigned)batch), dim3(256), 0, st, d_sb_ws,
+                     SL, d_dia_off, d_z, stride_z, ncols);
   SC_HIP(ctx, hipGetLastError());
-  SC_HIP(ctx, hipStreamSynchronize(st));
   return SC_OK;
 }
 
