@@ -93,12 +93,22 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
 
   // (a0) reflector scalars and w
   if (j >= 1) {
-    if (tid < kB) {
-      double g = 0.0;
-      if (tid >= prev)
-        for (int ch = 0; ch < nchunks; ++ch) g += part_in[(size_t)ch * kB + tid];
-      red[tid] = g;   // tail Gram row of column prev
+    {
+      // tail Gram row of column prev: sum of the chunks' partial rows, four threads per column, loads four deep
+      const int cq = tid & 63, qq = tid >> 6;
+      double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+      int ch = qq;
+      for (; ch + 12 < nchunks; ch += 16) {
+        g0 += part_in[(size_t)ch * kB + cq];
+        g1 += part_in[(size_t)(ch + 4) * kB + cq];
+        g2 += part_in[(size_t)(ch + 8) * kB + cq];
+        g3 += part_in[(size_t)(ch + 12) * kB + cq];
+      }
+      for (; ch < nchunks; ch += 4) g0 += part_in[(size_t)ch * kB + cq];
+      red[qq * kB + cq] = (g0 + g1) + (g2 + g3);
     }
+    __syncthreads();
+    if (tid < kB) red[tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
     __syncthreads();
     if (tid == 0) {
       const double alpha = piv_in[prev];
@@ -314,7 +324,9 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
   double* ab = sb + SL.ab;
   const int S = s / kG, cc = s - S * kG;
-  const size_t dia = (size_t)dia_off[S] + k;
+  // diamonds of group S start at sum_{S' < S} chase_len(n, 64 S') = S K0 - S (S - 1) / 2  (K0 = chase_len(n, 0))
+  const size_t dia = (size_t)S * chase_len(n, 0) - (size_t)S * (S - 1) / 2 + k;
+  (void)dia_off;
   // diamonds are stored row-major (sweep index contiguous): element (row r, sweep c) at [c + r * kG]
   double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kG + cc;   // this reflector's first entry (row cc, column cc)
   const int tid = threadIdx.x;
