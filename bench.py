@@ -13,9 +13,13 @@ data-path collective (weak scaling: B structures per GPU); RCCL is only used for
 max-over-ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel (k_symv_tiles, HBM-bound): algorithmic bytes / kernel time vs 8 TB/s;
-                kernel time from HIP events around every launch of that kernel on the solver's stream,
-                taken in one extra profiled step right after the timed region (profiling adds host
+  roofline      dominant kernel.  With 16 structures per GPU the eigensolver takes its two-stage path and the
+                dominant kernel is k_bt2_fused (back-transformation of the bulge-chasing reflectors, f64-MFMA
+                bound): algorithmic flops (applying each reflector of length L to the 6000 eigenvector columns,
+                4 L flops per column) / kernel time vs the 78.6 TFLOP/s f64 matrix peak.  On the one-stage
+                path (few structures in flight) it is k_symv_tiles (HBM-bound): algorithmic bytes / kernel
+                time vs 8 TB/s.  Kernel time from HIP events around the kernel's launches on the solver's
+                stream, taken in one extra profiled step right after the timed region (profiling adds host
                 syncs, so it is kept out of the timed steps)
   cpu_baseline  the oracle (NumPy restatement of compute_hessian + numpy.linalg.eigh = LAPACK dsyevd,
                 the reference's own driver) timed on this box's host cores on ONE structure
@@ -39,6 +43,23 @@ def symv_algorithmic_bytes(n):
     """Lower-triangle elements of the trailing matrix, read once per Householder column (8 B each)."""
     m = np.arange(n - 1, 1, -1, dtype=np.float64)   # m_c = n - c - 1 for c = 0 .. n-3
     return float(np.sum(m * (m + 1) / 2) * 8.0)
+
+
+def bt2_flops(n, ncols):
+    """
+    k_bt2_fused, per matrix: (algorithmic, executed) flops.  Sweep s (0 .. n-3) of the bulge chase leaves reflectors
+    of length min(64, n - r0) at rows r0 = s + 1 + 64 k; applying one of length L to a column costs 4 L flops.
+    The kernel applies them 64 sweeps at a time as compact-WY "diamonds" padded to 128 x 64: 4 * 64 * 128 flops
+    per diamond and column.
+    """
+    s = np.arange(0, n - 2, dtype=np.int64)
+    total_len = 0
+    for k in range((n - 1 + 63) // 64):
+        r0 = s + 1 + 64 * k
+        total_len += int(np.clip(n - r0, 0, 64).sum())
+    ngroups = (n - 2 + 63) // 64
+    ndia = sum((n - 1 - 64 * g + 63) // 64 for g in range(ngroups))
+    return 4.0 * total_len * ncols, 4.0 * 64 * 128 * ndia * ncols
 
 
 def symv_traffic_per_launch(n, batch):
@@ -155,27 +176,49 @@ def main():
         torch.cuda.synchronize()
         t = solver.last_timings()
         solver.set_profiling(False)
-        launches = (n - 2)
-        bytes_per_launch = symv_algorithmic_bytes(n) * B / launches   # batched launch: B matrices
-        avg_ms = t["symv_ms"] / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {
-            "kernel": "k_symv_tiles",
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": symv_traffic_per_launch(n, B),
-            "launches_per_step": launches,
-            "algorithmic_bytes_per_launch": round(bytes_per_launch),
-            "avg_launch_ms": round(avg_ms, 5),
-            "measured": "HIP events around every launch, one extra profiled step after the timed region",
-        }
-        syr2k_flops = 2.0 / 3.0 * float(n) ** 3 * B
         phases = dict(t)
-        phases["syr2k_tflops"] = round(syr2k_flops / (t["syr2k_ms"] * 1e-3) / 1e12, 2) if t["syr2k_ms"] > 0 else None
-        phases["syr2k_frac_of_f64_mfma_peak"] = round(phases["syr2k_tflops"] / F64_MFMA_PEAK_TF, 4) if phases["syr2k_tflops"] else None
+        if t.get("two_stage"):
+            alg, executed = bt2_flops(n, n)
+            ms = t["bt2_fused_ms"]
+            achieved = alg * B / (ms * 1e-3) / 1e12
+            roofline = {
+                "kernel": "k_bt2_fused",
+                "bound": "mfma",
+                "achieved": round(achieved, 2),
+                "peak": F64_MFMA_PEAK_TF,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / F64_MFMA_PEAK_TF, 4),
+                "traffic": None,
+                "launches_per_step": 1,
+                "algorithmic_flops_per_launch": alg * B,
+                "executed_flops_per_launch": executed * B,
+                "executed_tflops": round(executed * B / (ms * 1e-3) / 1e12, 2),
+                "avg_launch_ms": round(ms, 3),
+                "measured": "HIP events around the launch, one extra profiled step after the timed region",
+            }
+            # stage 1 (band reduction): 4/3 n^3 flops per matrix in GEMMs + the panel QR
+            phases["band_reduction_tflops"] = round(4.0 / 3.0 * float(n) ** 3 * B / (t["band_reduction_ms"] * 1e-3) / 1e12, 2)
+        else:
+            launches = (n - 2)
+            bytes_per_launch = symv_algorithmic_bytes(n) * B / launches   # batched launch: B matrices
+            avg_ms = t["symv_ms"] / launches
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {
+                "kernel": "k_symv_tiles",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": symv_traffic_per_launch(n, B),
+                "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "avg_launch_ms": round(avg_ms, 5),
+                "measured": "HIP events around every launch, one extra profiled step after the timed region",
+            }
+            syr2k_flops = 2.0 / 3.0 * float(n) ** 3 * B
+            phases["syr2k_tflops"] = round(syr2k_flops / (t["syr2k_ms"] * 1e-3) / 1e12, 2) if t["syr2k_ms"] > 0 else None
+            phases["syr2k_frac_of_f64_mfma_peak"] = round(phases["syr2k_tflops"] / F64_MFMA_PEAK_TF, 4) if phases["syr2k_tflops"] else None
         w_gpu0 = w[0].cpu().numpy()
 
     if world > 1:

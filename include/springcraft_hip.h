@@ -198,13 +198,20 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
 int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
                           double* d_w, double* d_v);
 
+/* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when batch * n^2 >= 1.2e8 and
+ * n >= 1024, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the same eigenpairs to
+ * rounding (|dw| ~ 1e-14 |w|max); the choice only affects speed. */
+int sc_ctx_set_two_stage(sc_ctx* ctx, int mode);
+
 /* Bytes of device workspace sc_dev_eigh_f64 will hold for (n, batch) (allocated lazily, cached). */
 int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors);
 
 /* Per-phase device timings (ms, HIP events on the context's stream) of the most recent
  * sc_dev_eigh_f64 when profiling was enabled with sc_ctx_set_profiling(ctx, 1):
- * out[0]=tridiagonalisation, out[1]=tridiagonal eigensolver, out[2]=back-transformation,
- * out[3]=SYMV kernels only (sum), out[4]=SYR2K kernels only (sum), out[5]=reserved. */
+ * out[0]=tridiagonalisation, out[1]=tridiagonal eigensolver, out[2]=back-transformation, and
+ *   one-stage path (out[5] == 0): out[3]=SYMV kernels only (sum), out[4]=SYR2K kernels only (sum);
+ *   two-stage path (out[5] > 0):  out[3]=stage 1 (band reduction), out[4]=stage 2 (bulge chasing),
+ *                                 out[5]=the fused stage-2 back-transformation kernel alone. */
 int sc_ctx_set_profiling(sc_ctx* ctx, int enabled);
 int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
 

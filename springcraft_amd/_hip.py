@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
     "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
     "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
-    "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs",
+    "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage",
 ]
 
 
@@ -93,6 +93,28 @@ def library_path():
     return os.environ.get("SPRINGCRAFT_HIP_LIB", join(_PKG, _LIB_NAME))
 
 
+def _share_hip_runtime_with_torch():
+    """
+    PyTorch-ROCm wheels bundle their own libamdhip64.so.  A process must not end up with two HIP runtimes (whichever
+    initialises second sees no GPU), so when torch is installed its copy is loaded first — without importing torch —
+    and libspringcraft_hip.so binds to it, whatever the import order of the two packages.
+    """
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = join(dirname(spec.origin), "lib", "libamdhip64.so")
+    if exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load (once) and return the ctypes handle, with argument types declared."""
     global _lib
@@ -104,6 +126,7 @@ def lib():
             f"{path} not found: build it with `python springcraft_amd/csrc/build.py` "
             "(there is no CPU fallback)"
         )
+    _share_hip_runtime_with_torch()
     try:
         L = C.CDLL(path)
     except OSError as e:  # e.g. ROCm runtime missing
@@ -136,6 +159,7 @@ def lib():
         "sc_anm_eigen_range_f64": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, i64, i64, vp, vp]),
         "sc_dev_eigh_range_f64": (i32, [vp, vp, i64, i64, i64, i64, vp, vp]),
         "sc_ctx_set_profiling": (i32, [vp, i32]),
+        "sc_ctx_set_two_stage": (i32, [vp, i32]),
         "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
         "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
         "sc_modes_from_matrix": (i32, [vp, vp, i64, i32, P(vp)]),
@@ -194,6 +218,10 @@ class Context:
 
     def synchronize(self):
         self.check(self._L.sc_ctx_synchronize(self._h))
+
+    def set_two_stage(self, mode):
+        """Eigensolver path: None / -1 automatic, False / 0 one-stage, True / 1 two-stage tridiagonalisation."""
+        self.check(self._L.sc_ctx_set_two_stage(self._h, -1 if mode is None else int(mode)))
 
     def info(self):
         buf = C.create_string_buffer(256)

@@ -63,8 +63,12 @@ class DeviceBatchSolver:
     def last_timings(self):
         t = (C.c_double * 6)()
         self.ctx.check(self._L.sc_last_eigh_timings(self.ctx.handle, t))
-        return {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2],
-                "symv_ms": t[3], "syr2k_ms": t[4]}
+        out = {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2]}
+        if t[5] > 0:   # two-stage tridiagonalisation
+            out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_fused_ms=t[5])
+        else:
+            out.update(two_stage=False, symv_ms=t[3], syr2k_ms=t[4])
+        return out
 
     def assemble(self, coord):
         """coord: (batch, n_atoms, 3) float64 CUDA tensor -> self.matrix (Hessian / Kirchhoff)."""

@@ -649,6 +649,13 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
   return eigh_batched(ctx, d_a, n, batch, d_w, d_v);
 }
 
+int sc_ctx_set_two_stage(sc_ctx* ctx, int mode) {
+  if (!ctx) return SC_ERR_INVALID_ARG;
+  if (mode < -1 || mode > 1) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "mode must be -1, 0 or 1");
+  ctx->two_stage = mode;
+  return SC_OK;
+}
+
 int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors) {
   if (n <= 0 || batch <= 0) return 0;
   return (int64_t)eigh_workspace_bytes(n, batch, want_vectors != 0);

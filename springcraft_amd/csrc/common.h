@@ -26,6 +26,7 @@ struct sc_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
 
+  int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
   bool profiling = false;
   double last_timings[6] = {0, 0, 0, 0, 0, 0};
 };

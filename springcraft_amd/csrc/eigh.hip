@@ -48,21 +48,21 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
   return (size_t)off;
 }
 
-// Two-stage tridiagonalisation (twostage.hip) instead of the one-stage panel algorithm: SPRINGCRAFT_TWO_STAGE=1
-// forces it on, =0 off; by default matrices of order >= SPRINGCRAFT_TWO_STAGE_MIN use it.
-bool two_stage_for(int n) {
-  static const int mode = [] {
+// Two-stage tridiagonalisation (twostage.hip) instead of the one-stage panel algorithm.  The one-stage SYMV streams
+// 4/3 n^3 bytes per matrix and is bandwidth-bound as soon as a few matrices are in flight; the two-stage path does its
+// O(n^3) work in MFMA GEMMs but pays ~3 n short launches and twice the back-transformation flops.  Measured crossover
+// on MI355X (profiles/r01_two_stage_crossover.txt): batch * n^2 ~ 1.2e8 (n = 3000: 12 matrices, n = 6000: 4).
+// sc_ctx_set_two_stage(ctx, 1 / 0) or SPRINGCRAFT_TWO_STAGE=1 / 0 force it on / off.
+bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
+  static const int env_mode = [] {
     const char* e = getenv("SPRINGCRAFT_TWO_STAGE");
     return e ? atoi(e) : -1;
   }();
-  static const int min_n = [] {
-    const char* e = getenv("SPRINGCRAFT_TWO_STAGE_MIN");
-    return e ? atoi(e) : 1 << 30;
-  }();
+  const int mode = (ctx && ctx->two_stage >= 0) ? ctx->two_stage : env_mode;
   if (n < 4 * sb_band_width()) return false;
   if (mode == 0) return false;
   if (mode == 1) return true;
-  return n >= min_n;
+  return n >= 1024 && (double)batch * n * n >= 1.2e8;
 }
 
 struct Plan {
@@ -76,14 +76,14 @@ struct Plan {
   long long n_bt2 = 0;
 };
 
-Plan make_plan(int n, int batch, bool vectors) {
+Plan make_plan(const sc_ctx* ctx, int n, int batch, bool vectors) {
   Plan P;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   P.off_tri = take(tri_slab_doubles(n, &P.TL) * 8 * batch);
   const int npanels = (n + kNb - 1) / kNb;
   P.n_syr2k = npanels * batch;
-  P.two = two_stage_for(n);
+  P.two = two_stage_for(ctx, n, batch);
   if (P.two) {
     P.off_sb = take(sb_slab_doubles(n, vectors ? n : 0, &P.SL) * 8 * batch);
     P.off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
@@ -169,7 +169,7 @@ int sturm_bisect_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, 
 }
 
 size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors) {
-  return make_plan((int)n, (int)batch, want_vectors).total;
+  return make_plan(nullptr, (int)n, (int)batch, want_vectors).total;
 }
 
 int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double* d_w, double* d_v) {
@@ -177,7 +177,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   const int n = (int)n64, batch = (int)batch64;
   const bool vectors = d_v != nullptr;
   hipStream_t st = ctx->stream;
-  const Plan P = make_plan(n, batch, vectors);
+  const Plan P = make_plan(ctx, n, batch, vectors);
   SC_TRY(sc_reserve_ws(ctx, P.total));
   char* base = (char*)ctx->ws;
   double* tri_ws = (double*)(base + P.off_tri);
@@ -204,6 +204,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
 
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float ms_bt2 = 0.f;
   const bool prof = ctx->profiling;
   if (prof) {
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
@@ -232,8 +233,9 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    if (P.two)
-      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n));
+    if (P.two) {
+      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
+    }
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
                                  descs + P.n_syr2k + P.n_merge, P.two ? sb_band_width() : 1));
   }
@@ -249,7 +251,10 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     ctx->last_timings[2] = t23;
     ctx->last_timings[3] = ms_symv;
     ctx->last_timings[4] = ms_syr2k;
-    ctx->last_timings[5] = P.two ? 1.0 : 0.0;
+    // two-stage path: [3] = stage 1 (band reduction), [4] = stage 2 (bulge chasing), [5] = the fused kernel that
+    // back-transforms the stage-2 reflectors (k_bt2_fused); [5] = 0 marks the one-stage path
+    ctx->last_timings[5] = 0.0;
+    if (P.two) ctx->last_timings[5] = vectors ? ms_bt2 : 1e-9;
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
   SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads
@@ -268,55 +273,71 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   hipStream_t st = ctx->stream;
   const long long stride_a = (long long)n * n;
 
-  // workspace: tri slab | stein | bt slab | VT (n x n) | descriptors
+  // workspace: tri slab | [sb slab | diamond offsets] | stein | bt slab | VT (n x n) | descriptors
   TriLayout TL;
   BtLayout BL;
+  SbLayout SL;
+  const bool two = two_stage_for(ctx, n, batch);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   const size_t off_tri = take(tri_slab_doubles(n, &TL) * 8 * batch);
   const int npanels = (n + kNb - 1) / kNb;
-  size_t off_stein = 0, off_bt = 0, off_vt = 0;
+  size_t off_stein = 0, off_bt = 0, off_vt = 0, off_sb = 0, off_dia = 0;
   int n_bt = 0;
+  int n_tri_desc = npanels * batch;
+  if (two) {
+    off_sb = take(sb_slab_doubles(n, d_v ? m : 0, &SL) * 8 * batch);
+    off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
+    n_tri_desc = std::max(n_tri_desc, sb_desc_count(n, batch));
+  }
   if (d_v) {
     off_stein = take(stein_workspace_doubles(n, m) * 8 * batch);
     off_bt = take(bt_slab_doubles(n, &BL) * 8 * batch);
     off_vt = take((size_t)n * n * 8 * batch);
     n_bt = bt_desc_count(n, batch);
   }
-  const size_t n_desc = (size_t)npanels * batch + n_bt + 2 * (size_t)batch + 8;
+  const size_t n_desc = (size_t)n_tri_desc + n_bt + 2 * (size_t)batch + 8;
   const size_t off_desc = take(sizeof(GemmDesc) * n_desc);
   SC_TRY(sc_reserve_ws(ctx, off));
   char* base = (char*)ctx->ws;
   double* tri_ws = (double*)(base + off_tri);
+  double* sb_ws = (double*)(base + off_sb);
   GemmDesc* descs = (GemmDesc*)(base + off_desc);
 
   std::vector<GemmDesc> h((size_t)npanels * batch);
-  for (int p = 0; p < npanels; ++p) {
-    const int pend = std::min((p + 1) * kNb, n);
-    for (int b = 0; b < batch; ++b) {
-      double* ws = tri_ws + (size_t)b * TL.slab;
-      GemmDesc D{};
-      D.a = ws + TL.vw + pend; D.sa_i = 1; D.sa_k = n;
-      D.b = ws + TL.wv + pend; D.sb_k = n; D.sb_j = 1;
-      D.c = d_a + (size_t)b * stride_a + (size_t)pend * n + pend; D.ldc = n;
-      D.m = n - pend; D.n = n - pend; D.k = 2 * kNb;
-      D.alpha = -1.0; D.beta = 1.0;
-      D.lower_only = 1;
-      h[(size_t)p * batch + b] = D;
+  if (two) {
+    SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
+    SC_TRY(sytrd_2stage_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, sb_ws, SL, (int*)(base + off_dia), descs,
+                                nullptr, nullptr));
+  } else {
+    for (int p = 0; p < npanels; ++p) {
+      const int pend = std::min((p + 1) * kNb, n);
+      for (int b = 0; b < batch; ++b) {
+        double* ws = tri_ws + (size_t)b * TL.slab;
+        GemmDesc D{};
+        D.a = ws + TL.vw + pend; D.sa_i = 1; D.sa_k = n;
+        D.b = ws + TL.wv + pend; D.sb_k = n; D.sb_j = 1;
+        D.c = d_a + (size_t)b * stride_a + (size_t)pend * n + pend; D.ldc = n;
+        D.m = n - pend; D.n = n - pend; D.k = 2 * kNb;
+        D.alpha = -1.0; D.beta = 1.0;
+        D.lower_only = 1;
+        h[(size_t)p * batch + b] = D;
+      }
     }
+    SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+    float ms_symv = 0.f, ms_syr2k = 0.f;
+    SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_symv, &ms_syr2k));
   }
-  SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
-  float ms_symv = 0.f, ms_syr2k = 0.f;
-  SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_symv, &ms_syr2k));
-  GemmDesc* d2 = descs + (size_t)npanels * batch;
+  GemmDesc* d2 = descs + (size_t)n_tri_desc;
   if (!d_v) {
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, nullptr, 0, nullptr, d2));
   } else {
     const long long stride_x = (long long)n * m;
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, d_v, stride_x, (double*)(base + off_stein), d2));
+    if (two) SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m));
     // the back-transformation indexes its scratch with the matrix stride: VT lives in an n x n buffer per matrix
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, (double*)(base + off_bt), BL, d_v,
-                                 stride_x, m, (double*)(base + off_vt), d2 + 2 * batch));
+                                 stride_x, m, (double*)(base + off_vt), d2 + 2 * batch, two ? sb_band_width() : 1));
   }
   SC_HIP(ctx, hipStreamSynchronize(st));
   return SC_OK;

@@ -120,7 +120,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                          double* d_band_copy = nullptr);
 // Z <- Q2 Z (stage-2 reflectors)
 int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, const int* d_dia_off, double* d_z,
-                long long stride_z, int ncols);
+                long long stride_z, int ncols, float* ms_fused = nullptr);
 
 // ---- partial spectrum (stein.hip) -----------------------------------------------------------------------
 size_t stein_workspace_doubles(int n, int m);

@@ -9,7 +9,10 @@ sys.path.insert(0, ".")
 import springcraft_amd as sc  # noqa: E402
 from springcraft_amd.batch import DeviceBatchSolver  # noqa: E402
 
-for n_atoms, B in ((512, 1), (1000, 1), (1000, 8), (2000, 1), (2000, 16)):
+cases = ((512, 1), (1000, 1), (1000, 8), (2000, 1), (2000, 16))
+if len(sys.argv) > 1:   # N:B pairs
+    cases = tuple(tuple(int(x) for x in a.split(":")) for a in sys.argv[1:])
+for n_atoms, B in cases:
     box = 5.0 * n_atoms ** (1 / 3)
     coord = torch.from_numpy(np.stack([np.random.RandomState(s).rand(n_atoms, 3) * box for s in range(B)])).cuda()
     solver = DeviceBatchSolver(n_atoms, B, sc.InvariantForceField(13.0) if n_atoms < 2000 else sc.HinsenForceField())
