@@ -49,8 +49,8 @@ def bt2_flops(n, ncols):
     """
     k_bt2_fused, per matrix: (algorithmic, executed) flops.  Sweep s (0 .. n-3) of the bulge chase leaves reflectors
     of length min(64, n - r0) at rows r0 = s + 1 + 64 k; applying one of length L to a column costs 4 L flops.
-    The kernel applies them 64 sweeps at a time as compact-WY "diamonds" padded to 128 x 64: 4 * 64 * 128 flops
-    per diamond and column.
+    The kernel applies them 64 sweeps at a time as compact-WY "diamonds" (127 x 64 parallelograms) and skips the
+    k-steps that only meet structural zeros: 2 * 64 * (80 + 64 + 40) MFMA flops per diamond and column.
     """
     s = np.arange(0, n - 2, dtype=np.int64)
     total_len = 0
@@ -59,7 +59,7 @@ def bt2_flops(n, ncols):
         total_len += int(np.clip(n - r0, 0, 64).sum())
     ngroups = (n - 2 + 63) // 64
     ndia = sum((n - 1 - 64 * g + 63) // 64 for g in range(ngroups))
-    return 4.0 * total_len * ncols, 4.0 * 64 * 128 * ndia * ncols
+    return 4.0 * total_len * ncols, 2.0 * 64 * (80 + 64 + 40) * ndia * ncols
 
 
 def symv_traffic_per_launch(n, batch):

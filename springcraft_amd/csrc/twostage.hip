@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 
   // accumulators: zt[h][ni][r] <-> Z(row = win + 64 h + 16 w + fr, col = j0 + 16 ni + fk + 4 r)
   d4 zt[2][2];
-  double b1[32], b2[2][16];
+  double b1[20], b2[2][16];
 
   auto load_half = [&](int h, int row0) {   // rows row0 + 16 w + fr
     const int row = row0 + 16 * w + fr;
@@ -564,10 +564,13 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) Zs[phys][(16 * ni + fk + 4 * r) * LDH + 16 * w + fr] = zt[h][ni][r];
   };
-  auto fetch_b1 = [&](size_t dia) {   // VD[row 4 kk + fk][sweep 16 w + fr]
-    const double* vd = sb + SL.vd + dia * kDiaSize + 16 * w + fr + (size_t)fk * kG;
+  // The diamond is a parallelogram: sweep c is non-zero in rows c .. c + 63 only.  Wave w (sweeps 16 w .. 16 w + 15)
+  // therefore only needs rows 16 w .. 16 w + 79 of VD in the first product (20 of the 32 k-steps), and in the second
+  // product the rows 64 + 16 w .. of VT are zero for sweeps < 16 w (VT[r, c] = sum_l V[r, l] T[l, c], l >= r - 63).
+  auto fetch_b1 = [&](size_t dia) {   // VD[row 16 w + 4 kk + fk][sweep 16 w + fr], kk < 20
+    const double* vd = sb + SL.vd + dia * kDiaSize + 16 * w + fr + (size_t)(16 * w + fk) * kG;
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) b1[kk] = vd[(size_t)kk * 4 * kG];
+    for (int kk = 0; kk < 20; ++kk) b1[kk] = vd[(size_t)kk * 4 * kG];
   };
   auto fetch_b2 = [&](size_t dia) {   // VT[row 64 h + 16 w + fr][sweep 4 kk + fk]
     const double* vt = sb + SL.vt2 + dia * kDiaSize + 16 * w + fr + (size_t)fk * kDiaLd;
@@ -592,9 +595,10 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
       // ---- W1^T = Z^T VD
       d4 c1[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
 #pragma unroll
-      for (int kk = 0; kk < 32; ++kk) {
-        const double* zs = Zs[(kk >> 4) ^ par];
-        const int rr = (kk & 15) * 4 + fk;
+      for (int kk = 0; kk < 20; ++kk) {
+        const int kr = 4 * w + kk;                 // k-step (4 rows each) within the 128-row window
+        const double* zs = Zs[(kr >> 4) ^ par];
+        const int rr = (kr & 15) * 4 + fk;
         const double a0 = zs[fr * LDH + rr], a1 = zs[(16 + fr) * LDH + rr];
         c1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1[kk], c1[0], 0, 0, 0);
         c1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[kk], c1[1], 0, 0, 0);
@@ -609,10 +613,11 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const double a0 = W1s[(4 * kk + fk) * LDW + fr], a1 = W1s[(4 * kk + fk) * LDW + 16 + fr];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          zt[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[h][kk], zt[h][0], 0, 0, 0);
-          zt[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[h][kk], zt[h][1], 0, 0, 0);
+        zt[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[0][kk], zt[0][0], 0, 0, 0);
+        zt[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[0][kk], zt[0][1], 0, 0, 0);
+        if (kk >= 4 * w) {   // wave-uniform
+          zt[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[1][kk], zt[1][0], 0, 0, 0);
+          zt[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[1][kk], zt[1][1], 0, 0, 0);
         }
       }
       if (k + 1 < nk) fetch_b2((size_t)d0 + k + 1);
