@@ -47,6 +47,14 @@ int sc_reserve_scratch(sc_ctx* ctx, size_t bytes) {
   return SC_OK;
 }
 
+int sc_aux_stream(sc_ctx* ctx) {
+  if (ctx->aux_stream) return SC_OK;
+  SC_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  SC_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+  SC_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  return SC_OK;
+}
+
 namespace {
 
 int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
@@ -301,6 +309,12 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+    (void)hipEventDestroy(ctx->aux_fork);
+    (void)hipEventDestroy(ctx->aux_join);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

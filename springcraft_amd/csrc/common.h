@@ -16,6 +16,9 @@ struct sc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream + events for work that is independent of what runs on `stream` (created on first use)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   std::string err;
   int num_cus = 0;
 
@@ -50,6 +53,7 @@ int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);
 
 // Grow-only cached allocations.
 int sc_reserve_ws(sc_ctx* ctx, size_t bytes);
+int sc_aux_stream(sc_ctx* ctx);   // creates aux_stream / aux_fork / aux_join if needed
 int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -226,6 +226,14 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(sturm_bisect_batched(ctx, n, batch, tri_ws, P.TL, d_w, n));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
   } else {
+    if (P.two) {
+      // the diamonds' T factors do not depend on the tridiagonal eigenproblem: second stream, alongside the D&C
+      SC_TRY(sc_aux_stream(ctx));
+      SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
+      SC_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+      SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, ctx->aux_stream));
+      SC_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+    }
     double* dc_ws = (double*)(base + P.off_dc);
     double* bt_ws = (double*)(base + P.off_bt);
     double* q_tmp = (double*)(base + P.off_qtmp);
@@ -234,6 +242,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
     if (P.two) {
+      SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
       SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
     }
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
@@ -334,7 +343,10 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   } else {
     const long long stride_x = (long long)n * m;
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, d_v, stride_x, (double*)(base + off_stein), d2));
-    if (two) SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m));
+    if (two) {
+      SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, SL, st));
+      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m));
+    }
     // the back-transformation indexes its scratch with the matrix stride: VT lives in an n x n buffer per matrix
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, (double*)(base + off_bt), BL, d_v,
                                  stride_x, m, (double*)(base + off_vt), d2 + 2 * batch, two ? sb_band_width() : 1));

@@ -118,7 +118,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                          const TriLayout& TL, double* d_sb_ws, const SbLayout& SL, int* d_dia_off /* n/64 + 2 ints */,
                          GemmDesc* d_descs /* sb_desc_count */, float* ms_stage1, float* ms_stage2,
                          double* d_band_copy = nullptr);
-// Z <- Q2 Z (stage-2 reflectors)
+// Z <- Q2 Z (stage-2 reflectors): bt2_prepare (T factors; independent of Z, may run on another stream), then bt2_batched
+int bt2_prepare(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, hipStream_t st);
 int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, const int* d_dia_off, double* d_z,
                 long long stride_z, int ncols, float* ms_fused = nullptr);
 

@@ -829,20 +829,28 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
 }
 
 // ================================================================================================================
-// Z <- Q2 Z.  d_z: (batch) ncols columns of length n (ld n).  d_dia_off: the offsets uploaded by sytrd_2stage_batched.
+// T factors and V T of all diamonds, on `st` (they only depend on the bulge chase, not on Z).
+int bt2_prepare(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, hipStream_t st) {
+  if (n < 3 || SL.ndia == 0) return SC_OK;
+  for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
+    const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
+    hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// Z <- Q2 Z (after bt2_prepare).  d_z: (batch) ncols columns of length n (ld n).
 int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, const int* d_dia_off, double* d_z,
                 long long stride_z, int ncols, float* ms_fused) {
   hipStream_t st = ctx->stream;
   if (n < 3 || SL.ndia == 0 || ncols <= 0) return SC_OK;
   hipEvent_t ev[2] = {nullptr, nullptr};
   const bool prof = ctx->profiling && ms_fused;
-  if (prof)
+  if (prof) {
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
-  for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
-    const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
-    hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
+    SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
-  if (prof) SC_HIP(ctx, hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)((ncols + kNc - 1) / kNc), (unsigned)batch), dim3(256), 0, st, d_sb_ws,
                      SL, d_dia_off, d_z, stride_z, ncols);
   SC_HIP(ctx, hipGetLastError());
