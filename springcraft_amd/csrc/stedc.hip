@@ -426,17 +426,31 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
   const double rho = 2.0 * fabs(ws[DL.ee + nd.mid - 1]);
   const double rinv = 1.0 / rho;
 
-  auto fsum = [&](double dorg, double tau) -> double {
-    double s = 0.0;
+  // f and f' = sum zz_i^2 / (dl_i - lambda)^2 in one pass
+  auto fsum2 = [&](double dorg, double tau, double& fp) -> double {
+    double s = 0.0, sp = 0.0;
     if (z2) {
-      for (int i = lane; i < K; i += 64) s += z2[i] / ((dl[i] - dorg) - tau);
+      for (int i = lane; i < K; i += 64) {
+        const double r = 1.0 / ((dl[i] - dorg) - tau);
+        const double zr = z2[i] * r;
+        s += zr;
+        sp += zr * r;
+      }
     } else {
       for (int i = lane; i < K; i += 64) {
         const double z = zzg[i];
-        s += (z * z) / ((dl[i] - dorg) - tau);
+        const double r = 1.0 / ((dl[i] - dorg) - tau);
+        const double zr = z * z * r;
+        s += zr;
+        sp += zr * r;
       }
     }
+    fp = wave_sum_all(sp);
     return rinv + wave_sum_all(s);
+  };
+  auto fsum = [&](double dorg, double tau) -> double {
+    double fp;
+    return fsum2(dorg, tau, fp);
   };
 
   int org;
@@ -458,14 +472,42 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
     t_hi = half;
   }
   const double dorg = dl[org];
+  // Root of f in t = |tau| on (0, t_hi], kept in a bracket [lo_b, hi_b] of IEEE bit patterns (monotone map, so the
+  // bracket can always be halved whatever the magnitude of the root).  Iteration: Newton in the variable 1/t, i.e.
+  // the model f ~ c -+ s / t through the origin pole (exact when that pole dominates, quadratic otherwise),
+  // t_new = f' t^2 / (f' t + f) with f' taken with respect to t; a step that leaves the bracket, or is not finite,
+  // is replaced by the bit midpoint.  Once the step is below a few ulps the far side is probed so that the bracket
+  // closes to neighbouring doubles: same end state as plain bisection, in ~10 evaluations instead of ~62.
   unsigned long long lo_b = 0ull, hi_b = (unsigned long long)__double_as_longlong(t_hi);
-  for (int it = 0; it < 70 && hi_b - lo_b > 1ull; ++it) {
-    const unsigned long long mid_b = lo_b + ((hi_b - lo_b) >> 1);
-    const double t = __longlong_as_double((long long)mid_b);
-    const double f = fsum(dorg, positive ? t : -t);
+  unsigned long long t_b = hi_b - ((hi_b - lo_b) >> 1);
+  unsigned long long probe_dist = 4ull;
+  for (int it = 0; it < 90 && hi_b - lo_b > 1ull; ++it) {
+    const double t = __longlong_as_double((long long)t_b);
+    double fp;
+    const double f = fsum2(dorg, positive ? t : -t, fp);
     // positive: f increasing in t, f(0+) = -inf;  negative: f decreasing in t, f(0+) = +inf
     const bool go_up = positive ? (f < 0.0) : (f > 0.0);
-    if (go_up) lo_b = mid_b; else hi_b = mid_b;
+    if (go_up) lo_b = t_b; else hi_b = t_b;
+    if (hi_b - lo_b <= 1ull) break;
+    const unsigned long long mid_b = lo_b + ((hi_b - lo_b) >> 1);
+    const double fpt = positive ? fp : -fp;           // df/dt
+    const double den = fpt * t + f;
+    const double tn = fpt * t * t / den;
+    unsigned long long n_b = mid_b;
+    if (tn == tn && tn > 0.0 && tn < 1.7e308) {
+      const unsigned long long c_b = (unsigned long long)__double_as_longlong(tn);
+      if (c_b > lo_b && c_b < hi_b) {
+        n_b = c_b;
+        const unsigned long long step = c_b > t_b ? c_b - t_b : t_b - c_b;
+        if (step <= 4ull) {
+          // converged from one side: look a few ulps beyond (4, 32, 256, ...) on the side the bracket is still wide
+          const unsigned long long far = go_up ? c_b + probe_dist : (c_b > probe_dist ? c_b - probe_dist : 0ull);
+          n_b = (far > lo_b && far < hi_b) ? far : mid_b;
+          probe_dist *= 8ull;
+        }
+      }
+    }
+    t_b = n_b;
   }
   double t_best = __longlong_as_double((long long)hi_b);
   if (lo_b > 0ull) {
