@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--structures-per-gpu", type=int, default=16)
+    ap.add_argument("--structures-per-gpu", type=int, default=32)
     ap.add_argument("--n-atoms", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -519,15 +519,30 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__ sb_all, SbLayout SL,
                                                       const int* __restrict__ dia_off, double* __restrict__ z_all,
-                                                      long long stride_z, int ncols) {
+                                                      long long stride_z, int ncols, int batch, int xcd_map) {
   constexpr int LDH = kB + 2;      // Z window copy: [col][row in half], 66: conflict-free A-operand reads
   constexpr int LDW = kNc + 16;    // W1 copy: [sweep][col]
   __shared__ double Zs[2][kNc * LDH];
   __shared__ double W1s[kG * LDW];
   const int n = SL.n;
-  const double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
-  double* Z = z_all + (size_t)blockIdx.y * stride_z;
-  const int j0 = blockIdx.x * kNc;
+  // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and every workgroup
+  // streams all diamonds of its matrix through that L2.  With xcd_map the 1-D grid is decoded so that all column
+  // chunks of a matrix run on the same XCD (matrix b on XCD b mod 8): a diamond is then fetched over the fabric
+  // once per XCD-round instead of once per XCD and drifts less out of the L2.
+  int mat, chunk;
+  if (xcd_map) {
+    const int nchunk = (ncols + kNc - 1) / kNc;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    mat = xcd + 8 * (slot / nchunk);
+    chunk = slot % nchunk;
+    if (mat >= batch) return;
+  } else {
+    mat = blockIdx.y;
+    chunk = blockIdx.x;
+  }
+  const double* sb = sb_all + (size_t)mat * SL.slab;
+  double* Z = z_all + (size_t)mat * stride_z;
+  const int j0 = chunk * kNc;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
 
@@ -609,6 +624,19 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) W1s[(16 * w + fr) * LDW + 16 * ni + fk + 4 * r] = -c1[ni][r];
       __syncthreads();   // W1 complete; nobody reads the window copy any more
+      // the 64 rows that enter the window next are not touched by this diamond: fetch them now, behind the MFMAs
+      d4 zn[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+      if (k + 1 < nk) {
+        const int row = win + 128 + 16 * w + fr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = j0 + 16 * ni + fk + 4 * r;
+            const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
+            zn[ni][r] = (row < n && col < ncols) ? v : 0.0;
+          }
+      }
       // ---- Z^T -= W1^T VT^T
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
@@ -628,7 +656,8 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
         zt[0][1] = zt[1][1];
         copy_half_to_lds(0, par ^ 1);       // the old second half (updated) stays where it is, as the new first half
         win += 64;
-        load_half(1, win + 64);
+        zt[1][0] = zn[0];
+        zt[1][1] = zn[1];
         copy_half_to_lds(1, par);           // new rows go where the finished half was
         par ^= 1;
       } else {
@@ -851,8 +880,15 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
-  hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)((ncols + kNc - 1) / kNc), (unsigned)batch), dim3(256), 0, st, d_sb_ws,
-                     SL, d_dia_off, d_z, stride_z, ncols);
+  const int nchunk = (ncols + kNc - 1) / kNc;
+  if (batch >= 8) {
+    const int per_xcd = (batch + 7) / 8;   // matrices per XCD
+    hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)(8 * per_xcd * nchunk)), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
+                       d_z, stride_z, ncols, batch, 1);
+  } else {
+    hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)nchunk, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
+                       d_z, stride_z, ncols, batch, 0);
+  }
   SC_HIP(ctx, hipGetLastError());
   if (prof) {
     SC_HIP(ctx, hipEventRecord(ev[1], st));
