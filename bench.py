@@ -13,7 +13,7 @@ data-path collective (weak scaling: B structures per GPU); RCCL is only used for
 max-over-ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel.  With 16 structures per GPU the eigensolver takes its two-stage path and the
+  roofline      dominant kernel.  With 32 structures per GPU the eigensolver takes its two-stage path and the
                 dominant kernel is k_bt2_fused (back-transformation of the bulge-chasing reflectors, f64-MFMA
                 bound): algorithmic flops (applying each reflector of length L to the 6000 eigenvector columns,
                 4 L flops per column) / kernel time vs the 78.6 TFLOP/s f64 matrix peak.  On the one-stage
