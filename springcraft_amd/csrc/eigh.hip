@@ -226,7 +226,10 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     SC_TRY(sturm_bisect_batched(ctx, n, batch, tri_ws, P.TL, d_w, n));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
   } else {
-    if (P.two) {
+    static const bool no_aux = getenv("SPRINGCRAFT_NO_AUX") != nullptr;
+    if (P.two && no_aux) {
+      SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, st));
+    } else if (P.two) {
       // the diamonds' T factors do not depend on the tridiagonal eigenproblem: second stream, alongside the D&C
       SC_TRY(sc_aux_stream(ctx));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
@@ -242,7 +245,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
                          descs + P.n_syr2k));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
     if (P.two) {
-      SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+      if (!no_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
       SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
     }
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,

@@ -104,7 +104,6 @@ struct SbLayout {
   long long ab;       // band storage 128 x n
   int ngroups;        // sweep groups (64 sweeps each)
   long long ndia;     // diamonds
-  int nslot;          // concurrently applied diamonds in the back-transformation
   long long vd, vt2;  // diamonds: V row-major (128 rows x 64 sweeps), V T column-major (ld 128)
   long long tau2;     // ndia x 64
 };

@@ -310,12 +310,12 @@ __host__ __device__ inline int chase_len(int n, int s) { return (n - 1 - s + kB 
 
 // Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
 __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
-                                                    const int* __restrict__ dia_off, int t) {
+                                                    int t) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
   double* D = E;   // the diagonal block is processed after E has gone back to memory: same buffer
   __shared__ double vp[kB], vn[kB], u[kB], red[4 * kB];
-  __shared__ double s_tau, s_beta, s_alpha2;
+  __shared__ double s_tau, s_beta;
 
   const int n = SL.n;
   const int k = (t & 1) + 2 * (int)blockIdx.x;
@@ -326,7 +326,6 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   const int S = s / kG, cc = s - S * kG;
   // diamonds of group S start at sum_{S' < S} chase_len(n, 64 S') = S K0 - S (S - 1) / 2  (K0 = chase_len(n, 0))
   const size_t dia = (size_t)S * chase_len(n, 0) - (size_t)S * (S - 1) / 2 + k;
-  (void)dia_off;
   // diamonds are stored row-major (sweep index contiguous): element (row r, sweep c) at [c + r * kG]
   double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kG + cc;   // this reflector's first entry (row cc, column cc)
   const int tid = threadIdx.x;
@@ -449,7 +448,6 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   // the reflector goes into its diamond
   if (tid < L) vd[(size_t)tid * kG] = vn[tid];
   if (tid == 0) sb[SL.tau2 + dia * kG + cc] = s_tau;
-  (void)s_alpha2;
 }
 
 // ================================================================================================================
@@ -690,14 +688,11 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   const int nsweep = std::max(n - 2, 0);
   L.ngroups = (nsweep + kG - 1) / kG;
   long long ndia = 0;
-  int maxlen = 0;
   for (int S = 0; S < L.ngroups; ++S) {
     const int len = (n - 1 - S * kG + kB - 1) / kB;
     ndia += len;
-    maxlen = std::max(maxlen, len);
   }
   L.ndia = ndia;
-  L.nslot = maxlen / 3 + 2;
   L.vd = take(ndia * kDiaSize);
   L.vt2 = take(ndia * kDiaSize);
   L.tau2 = take(ndia * kG);
@@ -841,7 +836,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const int t_max = 2 * (n - 3) + chase_len(n, n - 3) - 1;
     const int gx = chase_len(n, 0) / 2 + 1;
     for (int t = 0; t <= t_max; ++t)
-      hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off, t);
+      hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t);
   }
   hipLaunchKernelGGL(k_band_to_tri, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL,
                      d_tri_ws, TL);
