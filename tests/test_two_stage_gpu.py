@@ -131,3 +131,65 @@ def test_batched_solver_matches_one_stage(sc):
     for b in range(batch):
         h, _ = orc.compute_hessian(coord[b].cpu().numpy(), orc.invariant_ff(13.0))
         check_eigenvectors(h, w2[b], v2[b], tol_res=1e-11, tol_orth=1e-11)
+
+
+def test_7cal_prody_and_bio3d_goldens(sc):
+    """The reference's n = 5328 fixtures (tests/test_anm.py:87-142, :145-334) through the two-stage path."""
+    from tests.util import load_csv, structures
+
+    s = structures()
+    ca = s["7cal_coord"]
+    w, v = sc.ANM(ca, sc.InvariantForceField(13.0)).eigen()
+    ref = load_csv("prody_anm_13_ang_cutoff_evals_7cal.csv.gz")
+    check_eigenvalues(w, np.concatenate([np.zeros(6), ref[6:]]), 6, rtol=1e-5)
+    assert np.abs(v[:32] @ v.T - np.eye(len(w))[:32]).max() <= 1e-10
+    # mass-weighted Hinsen Hessian (Bio3D): rtol 5e-3 / atol 2e-3 as in the reference's test
+    atoms = sc.AtomArray(len(ca))
+    atoms.coord = ca
+    atoms.res_name = s["7cal_res_name"]
+    masses = load_csv("bio3d_mass_7cal.csv.gz")
+    w, _ = sc.ANM(atoms, sc.HinsenForceField(), masses=masses).eigen()
+    assert np.allclose(w[6:], load_csv("bio3d_anm_calpha_ff_evals_mw_7cal.csv.gz")[6:], rtol=5e-3, atol=2e-3)
+
+
+def test_gnm_large(sc):
+    """Kirchhoff matrices (integer entries, many equal eigenvalues) through the two-stage path."""
+    n_atoms = 1100
+    coord = synthetic_coord(n_atoms, 4)
+    w, v = sc.GNM(coord, sc.InvariantForceField(10.0)).eigen()
+    k, _ = orc.compute_kirchhoff(coord, orc.invariant_ff(10.0))
+    w_ref = np.linalg.eigvalsh(k)
+    check_eigenvalues(w, w_ref, 1)
+    check_eigenvectors(k, w, v, tol_res=1e-11, tol_orth=1e-11)
+
+
+def test_batched_ragged_order(sc):
+    """Batch of matrices whose order is not a multiple of anything (n = 1030), device API, both paths compared."""
+    import ctypes as C
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    n, batch = 1030, 5
+    rs = np.random.RandomState(5)
+    mats = np.stack([sym(rs, n) for _ in range(batch)])
+    L = _hip.lib()
+    ctx = _hip.Context(0)
+    out = {}
+    for mode in (True, False):
+        ctx.set_two_stage(mode)
+        a = torch.from_numpy(mats.copy()).cuda()
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(v.data_ptr())))
+        ctx.synchronize()
+        out[mode] = (w.cpu().numpy(), v.cpu().numpy())
+    for b in range(batch):
+        w_ref = np.linalg.eigvalsh(mats[b])
+        for mode in (True, False):
+            w, v = out[mode][0][b], out[mode][1][b]
+            assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+            check_eigenvectors(mats[b], w, v, tol_res=1e-11, tol_orth=1e-11)
+    ctx.close()
