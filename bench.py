@@ -13,7 +13,7 @@ data-path collective (weak scaling: B structures per GPU); RCCL is only used for
 max-over-ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel.  With 32 structures per GPU the eigensolver takes its two-stage path and the
+  roofline      dominant kernel.  With 64 structures per GPU the eigensolver takes its two-stage path and the
                 dominant kernel is k_bt2_fused (back-transformation of the bulge-chasing reflectors, f64-MFMA
                 bound): algorithmic flops (applying each reflector of length L to the 6000 eigenvector columns,
                 4 L flops per column) / kernel time vs the 78.6 TFLOP/s f64 matrix peak.  On the one-stage
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--structures-per-gpu", type=int, default=32)
+    ap.add_argument("--structures-per-gpu", type=int, default=64)
     ap.add_argument("--n-atoms", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
