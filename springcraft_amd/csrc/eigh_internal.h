@@ -99,6 +99,7 @@ struct SbLayout {
   long long vw, wv;   // [V|W], [W|V] panels, n x 128
   long long xv;       // [X1|X2|V], n x 192
   long long qrpart, qrpiv;   // panel-QR partial Gram rows / pivot row (two copies each)
+  long long qrpart8;         // blocked panel QR: per-chunk partial products of an inner block, nchunk x 8 x 64
   long long small;    // split-K slices of V^T [X1|X2|V]
   long long cmat;     // [T; T; -S/2], 192 x 64
   long long ab;       // band storage 128 x n

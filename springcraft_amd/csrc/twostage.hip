@@ -17,6 +17,7 @@
 //
 // Role in the reference: part of np.linalg.eigh (LAPACK dsyevd) at nma.py:61; LAPACK itself uses the one-stage dsytrd.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "eigh_internal.h"
@@ -64,7 +65,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Grid (chunks, batch), 256 threads; the chunk's columns j-1 .. kB-1 live in LDS for the duration of the launch.
 __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, long long stride_a,
                                                   double* __restrict__ tri_all, TriLayout TL,
-                                                  double* __restrict__ sb_all, SbLayout SL, int j0, int j, int nr) {
+                                                  double* __restrict__ sb_all, SbLayout SL, int j0, int j, int nr,
+                                                  int c_end) {
+  // c_end: columns j .. c_end-1 are updated (kB: the whole rest of the panel; blocked panels: the rest of the
+  // 8-column inner block, the other columns get the inner block's reflectors at once from k_pqr_blk_a / _b)
   constexpr int LD = kQrRows + 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* P = sm;                      // [kB][LD]   P[c * LD + r]
@@ -130,13 +134,13 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     const int r = tid & (kQrRows - 1), half = tid >> 7;
     const int rl = row_base + r;
     const double* src = A + (size_t)j0 * n + r0 + std::min(rl, m - 1);
-    for (int c = c_lo + half; c < kB; c += 16) {
+    for (int c = c_lo + half; c < c_end; c += 16) {
       double t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+        if (c + 2 * u < c_end) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
     }
   }
   __syncthreads();
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     }
     __syncthreads();
     // (a2) P[:, c] -= v w_c
-    if (c >= j) {
+    if (c >= j && c < c_end) {
       const double w = wv[c];
 #pragma unroll 8
       for (int r = q * 32; r < q * 32 + 32; ++r) P[c * LD + r] -= vv[r] * w;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   if (j < nr) {
     // (b) tail Gram row of column j over this chunk: rows with local index > j
     double acc = 0.0;
-    if (c >= j) {
+    if (c >= j && c < c_end) {
 #pragma unroll 8
       for (int r = q * 32; r < q * 32 + 32; ++r) {
         const int rl = row_base + r;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     __syncthreads();
     if (tid < kB) {
       part_out[(size_t)chunk * kB + tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
-      if (chunk == 0 && tid >= j) piv_out[tid] = P[tid * LD + j];   // pivot row (alpha at [j])
+      if (chunk == 0 && tid >= j && tid < c_end) piv_out[tid] = P[tid * LD + j];   // pivot row (alpha at [j])
     }
   } else {
     // last launch of the panel: columns without a reflector (short last panel) are zero in the V buffers
@@ -208,7 +212,245 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     const int r = tid & (kQrRows - 1), half = tid >> 7;
     const int rl = row_base + r;
     if (rl < m)
-      for (int cc = c_lo + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
+      for (int cc = c_lo + half; cc < c_end; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
+  }
+}
+
+// ---- blocked panels: the 8 reflectors of an inner block [c0, c0+8) applied to the columns to their right at once ----
+// k_pqr_blk_a: finishes reflector c0+7 (the inner block's last) and forms, per 128-row chunk, the partial products
+//   M[i][c] = v_{c0+i} . P[:, c]  for c = c0 .. kB-1  (the first 8 columns are the Gram matrix of the block's reflectors).
+// k_pqr_blk_b: sums them, builds the 8 x 8 T factor, W = T^T M, updates P[:, c] -= V W for c >= c0+8 and leaves the
+//   tail Gram row / pivot row of column c0+8 for the next inner block's first column launch.
+constexpr int kIb = 8;
+
+// explicit form of the inner block's reflectors in the LDS copy of chunk 0 (memory keeps R above the pivots)
+__device__ __forceinline__ void blk_explicit_v(double* P, int LD, int c0, int ncols, int row_base) {
+  if (row_base != 0) return;   // pivot rows are local rows c0 .. c0+7 of the first chunk
+  for (int idx = threadIdx.x; idx < ncols * kB; idx += 256) {
+    const int i = idx / kB, r = idx % kB;   // rows 0..63 suffice (pivots < 64)
+    const int piv = c0 + i;
+    if (r < piv) P[(c0 + i) * LD + r] = 0.0;
+    else if (r == piv) P[(c0 + i) * LD + r] = 1.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, long long stride_a,
+                                                   double* __restrict__ tri_all, TriLayout TL,
+                                                   double* __restrict__ sb_all, SbLayout SL, int j0, int c0) {
+  constexpr int LD = kQrRows + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* P = sm;                      // [kB][LD]
+  double* vv = sm + kB * LD;           // [kQrRows]
+  double* red = vv + kQrRows;          // [4][2][kB]
+  __shared__ double s_scale, s_beta, s_tau;
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const int chunk = blockIdx.x, nchunks = gridDim.x;
+  const int row_base = chunk * kQrRows;
+  const int tid = threadIdx.x;
+  const int prev = c0 + kIb - 1;
+  const int nchunk_cap = (n + kQrRows - 1) / kQrRows + 1;
+  const double* part_in = sb + SL.qrpart + (size_t)(prev & 1) * nchunk_cap * kB;
+  const double* piv_in = sb + SL.qrpiv + (size_t)(prev & 1) * (kB + 8);
+
+  // scalars of reflector prev
+  {
+    double g = 0.0;
+    for (int ch = tid; ch < nchunks; ch += 256) g += part_in[(size_t)ch * kB + prev];
+    g = wave_sum(g);
+    if ((tid & 63) == 0) red[tid >> 6] = g;
+    __syncthreads();
+    if (tid == 0) {
+      const HH h = householder(piv_in[prev], (red[0] + red[1]) + (red[2] + red[3]));
+      s_scale = h.scale; s_beta = h.beta; s_tau = h.tau;
+      if (chunk == 0) tri[TL.tau + j0 + prev] = h.tau;
+    }
+  }
+  // chunk (columns c0 .. kB-1) -> LDS
+  {
+    const int r = tid & (kQrRows - 1), half = tid >> 7;
+    const int rl = row_base + r;
+    const double* src = A + (size_t)j0 * n + r0 + std::min(rl, m - 1);
+    for (int c = c0 + half; c < kB; c += 16) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+    }
+  }
+  __syncthreads();
+  // v of reflector prev: to memory (v below the pivot, beta at it), to the panel buffers, explicit form in LDS
+  if (tid < kQrRows) {
+    const int rl = row_base + tid;
+    double v = 0.0;
+    if (rl < m) v = rl > prev ? s_scale * P[prev * LD + tid] : (rl == prev ? 1.0 : 0.0);
+    if (rl < m) {
+      if (rl > prev) A[(size_t)(j0 + prev) * n + r0 + rl] = v;
+      else if (rl == prev) A[(size_t)(j0 + prev) * n + r0 + rl] = s_beta;
+      const size_t row = (size_t)r0 + rl;
+      sb[SL.vw + (size_t)prev * n + row] = v;
+      sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
+      sb[SL.xv + (size_t)(2 * kB + prev) * n + row] = v;
+    }
+    P[prev * LD + tid] = v;
+  }
+  __syncthreads();
+  blk_explicit_v(P, LD, c0, kIb - 1, row_base);
+  __syncthreads();
+  // M partial: thread (c, q): 8 dot products over its 32 rows
+  const int c = tid & 63, q = tid >> 6;
+  double acc[kIb];
+#pragma unroll
+  for (int i = 0; i < kIb; ++i) acc[i] = 0.0;
+  if (c >= c0) {
+#pragma unroll 4
+    for (int r = q * 32; r < q * 32 + 32; ++r) {
+      const double x = P[c * LD + r];
+#pragma unroll
+      for (int i = 0; i < kIb; ++i) acc[i] += P[(c0 + i) * LD + r] * x;
+    }
+  }
+  double* p8 = sb + SL.qrpart8 + (size_t)chunk * kIb * kB;
+#pragma unroll
+  for (int pass = 0; pass < kIb / 2; ++pass) {
+    red[(q * 2 + 0) * kB + c] = acc[2 * pass];
+    red[(q * 2 + 1) * kB + c] = acc[2 * pass + 1];
+    __syncthreads();
+    if (tid < 2 * kB) {
+      const int h = tid >> 6, cc = tid & 63;
+      p8[(size_t)(2 * pass + h) * kB + cc] =
+          (red[(0 * 2 + h) * kB + cc] + red[(1 * 2 + h) * kB + cc]) + (red[(2 * 2 + h) * kB + cc] + red[(3 * 2 + h) * kB + cc]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, long long stride_a,
+                                                   const double* __restrict__ tri_all, TriLayout TL,
+                                                   double* __restrict__ sb_all, SbLayout SL, int j0, int c0) {
+  constexpr int LD = kQrRows + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* P = sm;                      // [kB][LD]
+  double* Ms = sm + kB * LD;           // [kIb][kB]  M, later W
+  double* red = Ms + kIb * kB;         // [4][kB]
+  __shared__ double T[kIb][kIb];
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  const double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const int chunk = blockIdx.x, nchunks = gridDim.x;
+  const int row_base = chunk * kQrRows;
+  const int tid = threadIdx.x;
+  const int jn = c0 + kIb;             // first column to the right = next pivot column
+  const int nchunk_cap = (n + kQrRows - 1) / kQrRows + 1;
+  double* part_out = sb + SL.qrpart + (size_t)(jn & 1) * nchunk_cap * kB;
+  double* piv_out = sb + SL.qrpiv + (size_t)(jn & 1) * (kB + 8);
+
+  // chunk (columns c0 .. kB-1) -> LDS (issued first: the loads fly while the partial products are summed)
+  {
+    const int r = tid & (kQrRows - 1), half = tid >> 7;
+    const int rl = row_base + r;
+    const double* src = A + (size_t)j0 * n + r0 + std::min(rl, m - 1);
+    for (int c = c0 + half; c < kB; c += 16) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+    }
+  }
+  // M = sum of the chunks' partial products
+  for (int idx = tid; idx < kIb * kB; idx += 256) {
+    const double* p8 = sb + SL.qrpart8 + idx;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    int ch = 0;
+    for (; ch + 3 < nchunks; ch += 4) {
+      g0 += p8[(size_t)ch * kIb * kB];
+      g1 += p8[(size_t)(ch + 1) * kIb * kB];
+      g2 += p8[(size_t)(ch + 2) * kIb * kB];
+      g3 += p8[(size_t)(ch + 3) * kIb * kB];
+    }
+    for (; ch < nchunks; ++ch) g0 += p8[(size_t)ch * kIb * kB];
+    Ms[idx] = (g0 + g1) + (g2 + g3);
+  }
+  __syncthreads();
+  // T (larft, forward columnwise) of the inner block: G[l][q] = Ms[l][c0 + q]
+  if (tid == 0) {
+    for (int qq = 0; qq < kIb; ++qq) {
+      const double tau = tri[TL.tau + j0 + c0 + qq];
+      for (int a = 0; a < qq; ++a) {
+        double s2 = 0.0;
+        for (int l = a; l < qq; ++l) s2 += T[a][l] * Ms[l * kB + c0 + qq];
+        T[a][qq] = -tau * s2;
+      }
+      T[qq][qq] = tau;
+      for (int a = qq + 1; a < kIb; ++a) T[a][qq] = 0.0;
+    }
+  }
+  __syncthreads();
+  // W = T^T M (in place, column by column: each thread owns column c)
+  if (tid < kB && tid >= jn) {
+    double mcol[kIb], wcol[kIb];
+#pragma unroll
+    for (int l = 0; l < kIb; ++l) mcol[l] = Ms[l * kB + tid];
+#pragma unroll
+    for (int i = 0; i < kIb; ++i) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int l = 0; l <= i; ++l) s2 += T[l][i] * mcol[l];
+      wcol[i] = s2;
+    }
+#pragma unroll
+    for (int i = 0; i < kIb; ++i) Ms[i * kB + tid] = wcol[i];
+  }
+  __syncthreads();
+  blk_explicit_v(P, LD, c0, kIb, row_base);
+  __syncthreads();
+  // P[:, c] -= V W[:, c]
+  const int c = tid & 63, q = tid >> 6;
+  if (c >= jn) {
+    double wcol[kIb];
+#pragma unroll
+    for (int i = 0; i < kIb; ++i) wcol[i] = Ms[i * kB + c];
+#pragma unroll 4
+    for (int r = q * 32; r < q * 32 + 32; ++r) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < kIb; ++i) s2 += P[(c0 + i) * LD + r] * wcol[i];
+      P[c * LD + r] -= s2;
+    }
+  }
+  __syncthreads();
+  // tail Gram row and pivot row of column jn over the next inner block
+  {
+    double acc = 0.0;
+    if (c >= jn && c < jn + kIb) {
+#pragma unroll 8
+      for (int r = q * 32; r < q * 32 + 32; ++r) {
+        const int rl = row_base + r;
+        if (rl > jn && rl < m) acc += P[jn * LD + r] * P[c * LD + r];
+      }
+    }
+    red[q * kB + c] = acc;
+    __syncthreads();
+    if (tid < kB) {
+      part_out[(size_t)chunk * kB + tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
+      if (chunk == 0 && tid >= jn && tid < jn + kIb) piv_out[tid] = P[tid * LD + jn];
+    }
+  }
+  // LDS -> chunk (columns to the right of the inner block)
+  {
+    const int r = tid & (kQrRows - 1), half = tid >> 7;
+    const int rl = row_base + r;
+    if (rl < m)
+      for (int cc = jn + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
   }
 }
 
@@ -681,6 +923,7 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   L.xv = take((long long)n * 3 * kB);
   L.qrpart = take((long long)2 * nchunk * kB);
   L.qrpiv = take(2 * (kB + 8));
+  L.qrpart8 = take((long long)nchunk * 8 * kB);
   L.small = take((long long)kSmallSplit * kB * 3 * kB);
   L.cmat = take(3 * kB * kB);
   L.ab = take((long long)kLdab * n);
@@ -805,13 +1048,32 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
 
   const size_t lds_qr = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kB + kQrRows + 4 * kB);
   const size_t lds_small = sizeof(double) * 4 * kB * (kB + 1);
+  const size_t lds_blk_a = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kQrRows + 8 * kB);
+  const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
+  static const bool blocked_qr = getenv("SPRINGCRAFT_QR_UNBLOCKED") == nullptr;
   for (int p = 0; p < npanels; ++p) {
     const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
     const int nr = std::min(kB, m - 1);
     const int nchunks = (m + kQrRows - 1) / kQrRows;
-    for (int j = 0; j <= nr; ++j)
-      hipLaunchKernelGGL(k_panel_qr, dim3((unsigned)nchunks, (unsigned)batch), dim3(256), lds_qr, st, d_a, stride_a,
-                         d_tri_ws, TL, d_sb_ws, SL, j0, j, nr);
+    const dim3 qgrid((unsigned)nchunks, (unsigned)batch);
+    if (nr == kB && blocked_qr) {
+      // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
+      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, 0, nr,
+                         kIb);
+      for (int c0 = 0; c0 < kB; c0 += kIb) {
+        for (int j = c0 + 1; j < c0 + kIb; ++j)
+          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, j,
+                             nr, c0 + kIb);
+        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, c0);
+        if (c0 + kIb < kB)
+          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
+                             c0);
+      }
+    } else {
+      for (int j = 0; j <= nr; ++j)
+        hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, j, nr,
+                           kB);
+    }
     const GemmDesc* g = d_descs + (size_t)p * 6 * batch;
     SC_TRY(launch_gemm_f64(ctx, g, 2 * batch, m, kB, kGemmTile, 1, false, true));
     SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit));
