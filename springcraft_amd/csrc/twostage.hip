@@ -694,7 +694,8 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 
 // ================================================================================================================
 // Diamonds: T factor and V T.  One workgroup per (diamond, matrix).  The diamond is held compactly in LDS
-// (Vc[c][i] = V[c + i, c], the 64 entries of reflector c), G and T share one buffer.
+// (Vc[c][i] = V[c + i, c], the 64 entries of reflector c), G and T share one buffer (G is only read by the first
+// wave's recurrence, which then writes T over it).
 __global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all, SbLayout SL, int dia0) {
   constexpr int LD = kG + 1;
   __shared__ double Vc[kG * LD];     // Vc[c * LD + i]
@@ -723,16 +724,25 @@ __global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all
     }
   }
   __syncthreads();
-  for (int qq = 0; qq < kG; ++qq) {
-    const double tq = tau[qq];
-    double s = 0.0;
-    if (tid < qq)
-      for (int l = tid; l < qq; ++l) s += GT[tid * LD + l] * GT[l * LD + qq];   // T[tid, l] (l < qq: already T) * G[l, qq]
-    __syncthreads();
-    if (tid < qq) GT[tid * LD + qq] = -tq * s;
-    if (tid == qq) GT[qq * LD + qq] = tq;
-    __syncthreads();
+  // T (larft, forward columnwise): T[0:q, q] = -tau_q T[0:q, 0:q] G[0:q, q], T[q, q] = tau_q.  Lane a of the first wave
+  // keeps row a of T in registers (T[a, l] = 0 for l < a), G comes as LDS broadcasts: 2016 fully unrolled FMAs per lane
+  // and no synchronisation inside the recurrence.
+  if (tid < kG) {
+    double trow[kG];
+#pragma unroll
+    for (int qq = 0; qq < kG; ++qq) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l < qq; ++l) s += trow[l] * GT[l * LD + qq];
+      const double tq = tau[qq];
+      trow[qq] = tid < qq ? -tq * s : (tid == qq ? tq : 0.0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): every lane has finished reading G before T overwrites it
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int qq = 0; qq < kG; ++qq) GT[tid * LD + qq] = trow[qq];
   }
+  __syncthreads();
   // VT[r, c] = sum_l V[r, l] T[l, c]   (128 x 64, column-major ld 128); V[r, l] = Vc[l][r - l] for 0 <= r - l < 64
   double* vt = sb + SL.vt2 + dia * kDiaSize;
   {
