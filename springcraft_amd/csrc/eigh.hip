@@ -212,9 +212,9 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   }
   float ms_symv = 0.f, ms_syr2k = 0.f;
   double* sb_ws = (double*)(base + P.off_sb);
+  SC_TRY(prepare_matrix_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL));
   if (P.two) {
-    // [3] / [4] then carry the stage-1 / stage-2 times, [5] = 1 marks the two-stage path
-    SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
+    // [3] / [4] then carry the stage-1 / stage-2 times
     SC_TRY(sytrd_2stage_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, sb_ws, P.SL, (int*)(base + P.off_dia),
                                 descs, &ms_symv, &ms_syr2k));
   } else {
@@ -224,6 +224,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
 
   if (!vectors) {
     SC_TRY(sturm_bisect_batched(ctx, n, batch, tri_ws, P.TL, d_w, n));
+    SC_TRY(unscale_values_batched(ctx, d_w, n, n, batch, tri_ws, P.TL));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
   } else {
     static const bool no_aux = getenv("SPRINGCRAFT_NO_AUX") != nullptr;
@@ -243,6 +244,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     double* u = (double*)(base + P.off_u);
     SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                          descs + P.n_syr2k));
+    SC_TRY(unscale_values_batched(ctx, d_w, n, n, batch, tri_ws, P.TL));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
     if (P.two) {
       if (!no_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
@@ -317,8 +319,8 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   GemmDesc* descs = (GemmDesc*)(base + off_desc);
 
   std::vector<GemmDesc> h((size_t)npanels * batch);
+  SC_TRY(prepare_matrix_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL));
   if (two) {
-    SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
     SC_TRY(sytrd_2stage_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, sb_ws, SL, (int*)(base + off_dia), descs,
                                 nullptr, nullptr));
   } else {
@@ -343,9 +345,11 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   GemmDesc* d2 = descs + (size_t)n_tri_desc;
   if (!d_v) {
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, nullptr, 0, nullptr, d2));
+    SC_TRY(unscale_values_batched(ctx, d_w, m, m, batch, tri_ws, TL));
   } else {
     const long long stride_x = (long long)n * m;
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, d_v, stride_x, (double*)(base + off_stein), d2));
+    SC_TRY(unscale_values_batched(ctx, d_w, m, m, batch, tri_ws, TL));
     if (two) {
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, SL, st));
       SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m));

@@ -17,13 +17,21 @@ struct TriLayout {
   long long npart;   // partial squared norms (<= n/256 + 1)
   long long wvpart;  // partial w~^T v
   long long d, e, tau;  // tridiagonal + reflector scalars (n each)
-  long long hscale;     // [0] = 1/(alpha - beta) of the current column (written by k_symv_tiles)
+  long long hscale;     // [0] = 1/(alpha - beta) of the current column (written by k_symv_tiles);
+                        // [1] = bit pattern of max |a_ij|, [2] = power-of-two factor the matrix was scaled by
 };
 
 // d_a: (batch) n x n column-major, lower triangle valid after the mirror pass; on exit column c holds
 // v_c (explicit leading 1) in rows c+1.., and ws holds d, e, tau.
 // NumPy (row-major) lower triangle -> column-major lower triangle, in place
 int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch);
+// mirror + scaling of badly scaled matrices (largest |entry| outside [1e-140, 1e140]) by a power of two; the factor
+// stays in the tri slab and unscale_values_batched divides the computed eigenvalues by it.  Call before
+// tridiag_batched / sytrd_2stage_batched (neither mirrors by itself).
+int prepare_matrix_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_tri_ws,
+                           const TriLayout& L);
+int unscale_values_batched(sc_ctx* ctx, double* d_w, long long stride_w, int m, int batch, const double* d_tri_ws,
+                           const TriLayout& L);
 
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv, float* ms_syr2k);

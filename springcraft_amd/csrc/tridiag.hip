@@ -444,6 +444,54 @@ __global__ void k_mirror_lower(double* __restrict__ a_all, long long stride_a, i
   }
 }
 
+// ---- scaling of badly scaled matrices (what LAPACK dsyevd does with dlansy / dlascl) -------------------------------
+// The Householder norms square the entries, so a matrix whose largest |entry| is outside [1e-140, 1e140] is multiplied
+// by a power of two that brings it to ~1 (exact), and the eigenvalues are divided by it afterwards.  Everything is
+// decided on the device: amax -> factor -> conditional in-place scaling, no host synchronisation.
+__global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__ a_all, long long stride_a, int n,
+                                                      double* __restrict__ ws_all, TriLayout L) {
+  const double* A = a_all + (size_t)blockIdx.y * stride_a;
+  unsigned long long* slot = reinterpret_cast<unsigned long long*>(ws_all + (size_t)blockIdx.y * L.slab + L.hscale + 1);
+  double m = 0.0;
+  const size_t total = (size_t)n * n;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
+    if (r >= c) m = fmax(m, fabs(A[idx]));   // fmax drops NaNs: they stay in the matrix and surface in the result
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  // the bit patterns of non-negative doubles are ordered like the values
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, (unsigned long long)__double_as_longlong(m));
+}
+
+__device__ __forceinline__ double matrix_scale_factor(double amax) {
+  if (!(amax > 0.0) || amax > 1.7e308) return 1.0;
+  if (amax >= 1e-140 && amax <= 1e140) return 1.0;
+  return ldexp(1.0, -ilogb(amax));
+}
+
+__global__ __launch_bounds__(256) void k_scale_lower(double* __restrict__ a_all, long long stride_a, int n,
+                                                     double* __restrict__ ws_all, TriLayout L) {
+  double* ws = ws_all + (size_t)blockIdx.y * L.slab;
+  const double amax = __longlong_as_double((long long)*reinterpret_cast<const unsigned long long*>(ws + L.hscale + 1));
+  const double f = matrix_scale_factor(amax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws[L.hscale + 2] = f;
+  if (f == 1.0) return;
+  double* A = a_all + (size_t)blockIdx.y * stride_a;
+  const size_t total = (size_t)n * n;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
+    if (r >= c) A[idx] *= f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_all, long long stride_w, int m,
+                                                        const double* __restrict__ ws_all, TriLayout L) {
+  const double f = ws_all[(size_t)blockIdx.y * L.slab + L.hscale + 2];
+  if (f == 1.0) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) w_all[(size_t)blockIdx.y * stride_w + i] /= f;
+}
+
 }  // namespace
 
 int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch) {
@@ -453,6 +501,30 @@ int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   return SC_OK;
 }
 
+// NumPy lower triangle -> column-major lower triangle, then the scaling described above (factor kept in the tri slab).
+int prepare_matrix_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_tri_ws,
+                           const TriLayout& L) {
+  SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
+  hipStream_t st = ctx->stream;
+  for (int b = 0; b < batch; ++b)
+    SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * L.slab + L.hscale + 1, 0, 2 * sizeof(double), st));
+  const unsigned gx = (unsigned)std::min<size_t>(1024, ((size_t)n * n + 255) / 256);
+  hipLaunchKernelGGL(k_absmax_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
+  hipLaunchKernelGGL(k_scale_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// eigenvalues of the scaled matrix -> eigenvalues of the caller's matrix; d_w: (batch) m values each
+int unscale_values_batched(sc_ctx* ctx, double* d_w, long long stride_w, int m, int batch, const double* d_tri_ws,
+                           const TriLayout& L) {
+  hipLaunchKernelGGL(k_unscale_values, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_w,
+                     stride_w, m, d_tri_ws, L);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv,
                     float* ms_syr2k) {
@@ -460,7 +532,6 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
   const int nb = L.nb;
   // persistent SYMV grid: 4 resident blocks per CU (LDS-limited), shared by the matrices of the batch
   const int symv_blocks = 4 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
-  SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   const bool prof = ctx->profiling && ms_symv && ms_syr2k;
   if (prof) {

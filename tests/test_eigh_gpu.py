@@ -294,3 +294,30 @@ def test_pinvh_matches_numpy(sc):
     gnm = sc.GNM(synthetic_coord(60, 2, 15.0), sc.InvariantForceField(7.0))
     k = gnm.kirchhoff
     assert np.allclose(gnm.covariance, np.linalg.pinv(k, hermitian=True, rcond=1e-6), atol=1e-10)
+
+
+@pytest.mark.parametrize("scale", [1e200, 1e-200, 3.7e160, 1e-170])
+def test_badly_scaled_matrices(sc, scale):
+    """
+    np.linalg.eigh (LAPACK dsyevd) rescales matrices whose norm is near the over / underflow thresholds; the squared
+    norms of the Householder steps would otherwise overflow / vanish.  Same here, on both tridiagonalisation paths.
+    """
+    from springcraft_amd import _hip
+
+    n = 300
+    a = sym(np.random.RandomState(9), n)
+    w_ref, _ = np.linalg.eigh(a)
+    ctx = _hip.context()
+    try:
+        for mode in (False, True):
+            ctx.set_two_stage(mode)
+            w, v = sc.nma.eigh(a * scale)
+            assert np.all(np.isfinite(w)) and np.all(np.isfinite(v))
+            assert np.abs(w / scale - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+            assert np.abs(a @ v.T - v.T * (w / scale)).max() <= 1e-11 * np.abs(w_ref).max()
+            w_only = sc.nma.eigh(a * scale, eigenvectors=False)
+            assert np.abs(w_only / scale - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+            ws, _ = sc.nma.eigh(a * scale, subset_by_index=(10, 20))
+            assert np.abs(ws / scale - w_ref[10:21]).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.set_two_stage(None)
