@@ -199,7 +199,7 @@ int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, in
                           double* d_w, double* d_v);
 
 /* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when batch * n^2 >= 1.2e8 and
- * n >= 1024, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the same eigenpairs to
+ * n >= 512, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the same eigenpairs to
  * rounding (|dw| ~ 1e-14 |w|max); the choice only affects speed. */
 int sc_ctx_set_two_stage(sc_ctx* ctx, int mode);
 

@@ -51,7 +51,8 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
 // Two-stage tridiagonalisation (twostage.hip) instead of the one-stage panel algorithm.  The one-stage SYMV streams
 // 4/3 n^3 bytes per matrix and is bandwidth-bound as soon as a few matrices are in flight; the two-stage path does its
 // O(n^3) work in MFMA GEMMs but pays ~3 n short launches and twice the back-transformation flops.  Measured crossover
-// on MI355X (profiles/r01_two_stage_crossover.txt): batch * n^2 ~ 1.2e8 (n = 3000: 12 matrices, n = 6000: 4).
+// on MI355X (profiles/r01_two_stage_crossover.txt): batch * n^2 ~ 1.2e8 (n = 3000: 12 matrices, n = 6000: 4), for
+// orders down to ~500.
 // sc_ctx_set_two_stage(ctx, 1 / 0) or SPRINGCRAFT_TWO_STAGE=1 / 0 force it on / off.
 bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
   static const int env_mode = [] {
@@ -62,7 +63,7 @@ bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
   if (n < 4 * sb_band_width()) return false;
   if (mode == 0) return false;
   if (mode == 1) return true;
-  return n >= 1024 && (double)batch * n * n >= 1.2e8;
+  return n >= 512 && (double)batch * n * n >= 1.2e8;
 }
 
 struct Plan {
