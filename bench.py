@@ -62,6 +62,23 @@ def bt2_flops(n, ncols):
     return 4.0 * total_len * ncols, 2.0 * 64 * (80 + 64 + 40) * ndia * ncols
 
 
+def bt2_traffic_per_launch(n, batch):
+    """
+    HBM / fabric bytes per k_bt2_fused launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE in separate runs; FETCH_SIZE x 2 as calibrated with tools/probe_fetch_width.hip for this access
+    width).  Only valid for the matrix order it was collected at; None otherwise.
+    """
+    path = os.path.join(ROOT, "profiles", "r01_bt2_pmc_fetch_write.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if int(d["n"]) != int(n):
+            return None
+        return round(float(d["hbm_bytes_per_launch_per_matrix_corrected"]) * batch)
+    except Exception:
+        return None
+
+
 def symv_traffic_per_launch(n, batch):
     """
     HBM bytes per k_symv_tiles launch from the PMC pass committed under profiles/ (rocprofv3 --pmc
@@ -188,7 +205,7 @@ def main():
                 "peak": F64_MFMA_PEAK_TF,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / F64_MFMA_PEAK_TF, 4),
-                "traffic": None,
+                "traffic": bt2_traffic_per_launch(n, B),
                 "launches_per_step": 1,
                 "algorithmic_flops_per_launch": alg * B,
                 "executed_flops_per_launch": executed * B,
