@@ -808,9 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int col = j0 + 16 * ni + fk + 4 * r;
         // unconditional load from a clamped address, masked afterwards
-        // Z streams through once per sweep group: non-temporal, so that it does not push the diamonds (which every
-        // workgroup of the matrix re-reads) out of the L2
-        const double v = __builtin_nontemporal_load(&Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)]);
+        const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
         zt[h][ni][r] = (row < n && col < ncols) ? v : 0.0;
       }
   };
@@ -822,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = j0 + 16 * ni + fk + 4 * r;
-        if (col < ncols) __builtin_nontemporal_store(zt[h][ni][r], &Z[(size_t)col * n + row]);
+        if (col < ncols) Z[(size_t)col * n + row] = zt[h][ni][r];
       }
   };
   auto copy_half_to_lds = [&](int h, int phys) {
@@ -885,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int col = j0 + 16 * ni + fk + 4 * r;
-            const double v = __builtin_nontemporal_load(&Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)]);
+            const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
             zn[ni][r] = (row < n && col < ncols) ? v : 0.0;
           }
       }
