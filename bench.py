@@ -3,30 +3,40 @@
 bench.py — headline benchmark of BASELINE.json: ANM modes/s (Hessian build + full eigensolve),
 N = 2000 C-alpha, HinsenForceField without cutoff (config C3), float64, all 6000 modes.
 
-    python bench.py --gpus N --steps K --warmup W [--structures-per-gpu B] [--n-atoms 2000]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c3|c4] [--structures-per-gpu B] [--n-atoms 2000]
 
-One "step" = one pass of the hot path over one batch of B synthetic structures per GPU whose
-coordinates are already resident in HBM: batched Hessian assembly (HIP) -> batched eigensolve (HIP),
-eigenvalues and eigenvectors left resident in HBM.  Structures are independent, so ranks share no
-data-path collective (weak scaling: B structures per GPU); RCCL is only used for the barrier and the
-max-over-ranks of the elapsed time.
+With ``--gpus N`` (N > 1) and no RANK in the environment the script starts the N ranks itself (a child
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...``, started
+before this process makes any GPU call) and exits with the child's code; under torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  WORLD_SIZE != --gpus is an error.
+
+--config c3 (default, the metric's configuration)
+    One "step" = one pass of the hot path over one batch of B synthetic structures per GPU whose coordinates are
+    already resident in HBM: batched Hessian assembly (HIP) -> batched eigensolve (HIP), eigenvalues and eigenvectors
+    left resident in HBM.  Structures are independent, so ranks share no data-path collective (weak scaling: B
+    structures per GPU); RCCL is only used for the barrier and the max-over-ranks of the elapsed time.
+--config c4 (BASELINE.json configs[3])
+    32 * N independent N = 1000 C-alpha ANM solves (InvariantForceField 13 A) through
+    ``springcraft_amd.batch.solve_sharded``: the root scatters the coordinate shards over RCCL, every rank solves its
+    32 structures, the root gathers the eigenvalues.  One step = one such call (the exchange steps are inside the
+    timed region); eigenvalues of every structure are checked against the oracle-independent residual on the ranks.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel.  With 64 structures per GPU the eigensolver takes its two-stage path and the
-                dominant kernel is k_bt2_fused (back-transformation of the bulge-chasing reflectors, f64-MFMA
-                bound): algorithmic flops (applying each reflector of length L to the 6000 eigenvector columns,
-                4 L flops per column) / kernel time vs the 78.6 TFLOP/s f64 matrix peak.  On the one-stage
-                path (few structures in flight) it is k_symv_tiles (HBM-bound): algorithmic bytes / kernel
-                time vs 8 TB/s.  Kernel time from HIP events around the kernel's launches on the solver's
-                stream, taken in one extra profiled step right after the timed region (profiling adds host
-                syncs, so it is kept out of the timed steps)
-  cpu_baseline  the oracle (NumPy restatement of compute_hessian + numpy.linalg.eigh = LAPACK dsyevd,
-                the reference's own driver) timed on this box's host cores on ONE structure
+  roofline      dominant kernel of the path taken (two-stage: k_bt2_fused, f64-MFMA bound: algorithmic flops of the
+                launch / its duration vs the 78.6 TFLOP/s f64 matrix peak; one-stage: k_symv_tiles, HBM bound).
+                Durations from HIP events on the solver's stream in one extra profiled step right after the timed
+                region.  ``traffic`` only from a PMC pass collected at the benchmarked (n, batch), else null.
+  rooflines     the other two rooflines BASELINE.json's north star names: ``assembly`` (k_hessian: 72 B per ordered
+                atom pair / kernel time vs 8 TB/s HBM) and ``band_reduction`` / ``syr2k`` (f64-MFMA fraction)
+  parity_gates  SURVEY.md section 8(d): contact counts, pair list, Kirchhoff (bit exact), Hessian (rel. Frobenius),
+                eigenvalues vs the CPU run, residual and orthogonality of several structures of the timed batch
+  cpu_baseline  the oracle (NumPy restatement of compute_hessian + numpy.linalg.eigh = LAPACK dsyevd, the
+                reference's own driver) on this box's host cores, median of 3 runs of ONE structure
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_MFMA_PEAK_TF = 78.6     # MI355X datasheet FP64 matrix; measured issue ceiling 47 TF (profiles/r01_probe_f64.txt)
+F64_MFMA_PEAK_TF = 78.6     # MI355X datasheet FP64 matrix (256 CUs x 4 SIMDs x 2.4 GHz x 32 flop/clk)
 
 
 def symv_algorithmic_bytes(n):
@@ -62,38 +72,22 @@ def bt2_flops(n, ncols):
     return 4.0 * total_len * ncols, 2.0 * 64 * (80 + 64 + 40) * ndia * ncols
 
 
-def bt2_traffic_per_launch(n, batch):
+def pmc_traffic(kind, n, batch):
     """
-    HBM / fabric bytes per k_bt2_fused launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
-    and WRITE_SIZE in separate runs; FETCH_SIZE x 2 as calibrated with tools/probe_fetch_width.hip for this access
-    width).  Only valid for the matrix order it was collected at; None otherwise.
+    HBM / fabric bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes).  Returned only when the
+    passes were collected at exactly this matrix order AND batch; None otherwise (no extrapolation).
     """
-    path = os.path.join(ROOT, "profiles", "r01_bt2_pmc_fetch_write.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if int(d["n"]) != int(n):
-            return None
-        return round(float(d["hbm_bytes_per_launch_per_matrix_corrected"]) * batch)
-    except Exception:
-        return None
-
-
-def symv_traffic_per_launch(n, batch):
-    """
-    HBM bytes per k_symv_tiles launch from the PMC pass committed under profiles/ (rocprofv3 --pmc
-    FETCH_SIZE in its own run, x2 gfx950 correction for 16-B-per-lane reads; see that file for the command).
-    Only valid for the matrix order it was collected at; None otherwise.
-    """
-    path = os.path.join(ROOT, "profiles", "r01_symv_pmc_fetch_size.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if int(d["n"]) != int(n):
-            return None
-        return round(float(d["hbm_read_bytes_per_launch_per_matrix_corrected"]) * batch)
-    except Exception:
-        return None
+    names = {"bt2": ["r02_bt2_pmc_fetch_write.json"], "symv": ["r02_symv_pmc_fetch_size.json", "r01_symv_pmc_fetch_size.json"]}
+    for name in names[kind]:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if int(d["n"]) == int(n) and int(d.get("batch", -1)) == int(batch):
+                return round(float(d["hbm_bytes_per_launch_corrected"]))
+        except Exception:
+            continue
+    return None
 
 
 def synthetic_coords(n_atoms, seeds):
@@ -105,8 +99,8 @@ def synthetic_coords(n_atoms, seeds):
     return out
 
 
-def cpu_baseline(n_atoms):
-    """Oracle on the host cores: one structure of the same workload (bounded sample)."""
+def cpu_baseline(n_atoms, ff_name, runs=3):
+    """Oracle on the host cores: one structure of the same workload, median of `runs` (bounded sample)."""
     from oracle import enm_oracle as orc
 
     try:
@@ -116,45 +110,90 @@ def cpu_baseline(n_atoms):
     except Exception:
         cores = os.cpu_count() or 1
     coord = synthetic_coords(n_atoms, [0])[0]
-    t0 = time.perf_counter()
-    h, _ = orc.compute_hessian(coord, orc.hinsen_ff())
-    t1 = time.perf_counter()
-    w, v = orc.eigen(h)
-    t2 = time.perf_counter()
+    ff = orc.hinsen_ff() if ff_name == "hinsen" else orc.invariant_ff(13.0)
+    ta, te = [], []
+    h = pairs = w = None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        h, pairs = orc.compute_hessian(coord, ff)
+        t1 = time.perf_counter()
+        w, _ = orc.eigen(h.copy())
+        t2 = time.perf_counter()
+        ta.append(t1 - t0)
+        te.append(t2 - t1)
+    tot = sorted(a + e for a, e in zip(ta, te))
+    med = tot[len(tot) // 2]
     return {
-        "value": 3 * n_atoms / (t2 - t0),
+        "value": 3 * n_atoms / med,
         "unit": "modes/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": f"1 structure N={n_atoms}: assembly {t1 - t0:.2f} s + numpy.linalg.eigh {t2 - t1:.2f} s",
-    }, w
+        "sample": (f"1 structure N={n_atoms}, median of {runs} runs: assembly {sorted(ta)[len(ta) // 2]:.2f} s + "
+                   f"numpy.linalg.eigh {sorted(te)[len(te) // 2]:.2f} s (runs: " + ", ".join(f"{t:.2f}" for t in tot) + " s)"),
+    }, h, pairs, w
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--structures-per-gpu", type=int, default=64)
-    ap.add_argument("--n-atoms", type=int, default=2000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def spawn_ranks(args):
+    """--gpus N without a rank environment: start the N ranks as a child job (nothing here has touched the GPU)."""
+    import socket
 
-    import torch
-    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: springcraft_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+def parity_gates(sc, solver, coord, w_all, v_all, n_atoms, cpu_h, cpu_pairs, cpu_w, torch):
+    """SURVEY.md section 8(d) gates on the batch that was just timed (device results vs the oracle's structure 0)."""
+    from oracle import enm_oracle as orc
+
+    gates = {}
+    c0 = coord[0].cpu().numpy()
+    # contact scan + pair list + Kirchhoff with an integer-valued force field: bit exact
+    k_gpu, p_gpu = sc.compute_kirchhoff(c0, sc.InvariantForceField(13.0))
+    k_cpu, p_cpu = orc.compute_kirchhoff(c0, orc.invariant_ff(13.0))
+    gates["kirchhoff_inv13_bit_exact"] = bool(np.array_equal(k_gpu, k_cpu))
+    gates["contact_counts_inv13_equal"] = bool(np.array_equal(np.diag(k_gpu).astype(np.int64), np.diag(k_cpu).astype(np.int64)))
+    gates["pairs_inv13_equal"] = bool(np.array_equal(p_gpu, p_cpu))
+    # the benchmarked force field: pair list and Hessian of structure 0
+    h_gpu, p_gpu = sc.compute_hessian(c0, sc.HinsenForceField())
+    gates["pairs_equal"] = bool(np.array_equal(p_gpu, cpu_pairs))
+    gates["n_pairs"] = int(len(p_gpu))
+    gates["hessian_rel_frobenius"] = float(np.linalg.norm(h_gpu - cpu_h) / np.linalg.norm(cpu_h))
+    # eigenvalues of structure 0 against LAPACK on the oracle's Hessian
+    w0 = w_all[0].cpu().numpy()
+    lam_max = float(np.abs(cpu_w).max())
+    gates["eigenvalues_max_rel_diff_nontrivial"] = float((np.abs(w0[6:] - cpu_w[6:]) / np.abs(cpu_w[6:])).max())
+    gates["trivial_modes_max_abs_over_lambda_max"] = float(np.abs(w0[:6]).max() / lam_max)
+    # residual and orthogonality of several structures of the batch (device arithmetic on the solver's outputs)
+    B = w_all.shape[0]
+    idx = sorted(set([0, B // 3, (2 * B) // 3, B - 1]))
+    w_keep = w_all[idx].clone()
+    v_keep = v_all[idx].clone()
+    h_all = solver.assemble(coord)           # eigh destroyed the matrices: assemble again
+    res, orth = [], []
+    eye = torch.eye(w_all.shape[1], dtype=torch.float64, device=w_all.device)
+    for j, b in enumerate(idx):
+        h, w, v = h_all[b], w_keep[j], v_keep[j]
+        r = h @ v.T - v.T * w[None, :]
+        res.append(float(torch.linalg.vector_norm(r, dim=0).max() / w.abs().max()))
+        orth.append(float((v @ v.T - eye).abs().max()))
+    gates["structures_checked"] = idx
+    gates["residual_max_over_norm"] = max(res)
+    gates["orthogonality_max"] = max(orth)
+    gates["pass"] = bool(
+        gates["kirchhoff_inv13_bit_exact"] and gates["pairs_inv13_equal"] and gates["pairs_equal"]
+        and gates["hessian_rel_frobenius"] <= 1e-12 and gates["eigenvalues_max_rel_diff_nontrivial"] <= 1e-5
+        and gates["trivial_modes_max_abs_over_lambda_max"] <= 1e-9 and gates["residual_max_over_norm"] <= 1e-5
+        and gates["orthogonality_max"] <= 1e-8)
+    return gates
+
+
+def run_c3(args, rank, world, torch, dist):
     import springcraft_amd as sc
     from springcraft_amd.batch import DeviceBatchSolver
 
@@ -183,99 +222,223 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel: one extra profiled step (rank 0 only) -------------------------
-    roofline = None
-    phases = None
-    w_gpu0 = None
+    out = None
     if rank == 0:
+        # ---- one extra profiled step: durations of the dominant kernel and of the phases (HIP events, solver's stream)
         solver.set_profiling(True)
         w, v = solver.solve(coord)
         torch.cuda.synchronize()
         t = solver.last_timings()
         solver.set_profiling(False)
         phases = dict(t)
+        rooflines = {}
         if t.get("two_stage"):
             alg, executed = bt2_flops(n, n)
             ms = t["bt2_fused_ms"]
             achieved = alg * B / (ms * 1e-3) / 1e12
             roofline = {
-                "kernel": "k_bt2_fused",
-                "bound": "mfma",
-                "achieved": round(achieved, 2),
-                "peak": F64_MFMA_PEAK_TF,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / F64_MFMA_PEAK_TF, 4),
-                "traffic": bt2_traffic_per_launch(n, B),
-                "launches_per_step": 1,
-                "algorithmic_flops_per_launch": alg * B,
+                "kernel": "k_bt2_fused", "bound": "mfma", "achieved": round(achieved, 2), "peak": F64_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TF, 4), "traffic": pmc_traffic("bt2", n, B),
+                "launches_per_step": 1, "algorithmic_flops_per_launch": alg * B,
                 "executed_flops_per_launch": executed * B,
-                "executed_tflops": round(executed * B / (ms * 1e-3) / 1e12, 2),
-                "avg_launch_ms": round(ms, 3),
+                "executed_tflops": round(executed * B / (ms * 1e-3) / 1e12, 2), "avg_launch_ms": round(ms, 3),
                 "measured": "HIP events around the launch, one extra profiled step after the timed region",
             }
-            # stage 1 (band reduction): 4/3 n^3 flops per matrix in GEMMs + the panel QR
-            phases["band_reduction_tflops"] = round(4.0 / 3.0 * float(n) ** 3 * B / (t["band_reduction_ms"] * 1e-3) / 1e12, 2)
+            # stage 1 (band reduction): 4/3 n^3 flops per matrix, all of them MFMA GEMMs (SYMM, W, SYR2K) + panel QR
+            br = 4.0 / 3.0 * float(n) ** 3 * B / (t["band_reduction_ms"] * 1e-3) / 1e12
+            rooflines["band_reduction"] = {
+                "bound": "mfma", "achieved": round(br, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(br / F64_MFMA_PEAK_TF, 4),
+                "what": "4/3 n^3 flops per matrix / duration of the whole stage incl. the panel QRs",
+            }
+            if t.get("syr2k_ms", 0) > 0:
+                sy = 2.0 / 3.0 * float(n) ** 3 * B / (t["syr2k_ms"] * 1e-3) / 1e12
+                rooflines["syr2k"] = {
+                    "bound": "mfma", "achieved": round(sy, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(sy / F64_MFMA_PEAK_TF, 4),
+                    "what": "trailing SYR2K launches of the band reduction alone: 2/3 n^3 flops per matrix / their duration",
+                }
         else:
             launches = (n - 2)
             bytes_per_launch = symv_algorithmic_bytes(n) * B / launches   # batched launch: B matrices
             avg_ms = t["symv_ms"] / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {
-                "kernel": "k_symv_tiles",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": symv_traffic_per_launch(n, B),
-                "launches_per_step": launches,
-                "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "kernel": "k_symv_tiles", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("symv", n, B),
+                "launches_per_step": launches, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "avg_launch_ms": round(avg_ms, 5),
                 "measured": "HIP events around every launch, one extra profiled step after the timed region",
             }
-            syr2k_flops = 2.0 / 3.0 * float(n) ** 3 * B
-            phases["syr2k_tflops"] = round(syr2k_flops / (t["syr2k_ms"] * 1e-3) / 1e12, 2) if t["syr2k_ms"] > 0 else None
-            phases["syr2k_frac_of_f64_mfma_peak"] = round(phases["syr2k_tflops"] / F64_MFMA_PEAK_TF, 4) if phases["syr2k_tflops"] else None
-        w_gpu0 = w[0].cpu().numpy()
+            if t["syr2k_ms"] > 0:
+                sy = 2.0 / 3.0 * float(n) ** 3 * B / (t["syr2k_ms"] * 1e-3) / 1e12
+                rooflines["syr2k"] = {"bound": "mfma", "achieved": round(sy, 2), "peak": F64_MFMA_PEAK_TF,
+                                      "unit": "TFLOP/s", "frac": round(sy / F64_MFMA_PEAK_TF, 4)}
+        # ---- assembly roofline: k_hessian alone (one launch per assemble), events on the same stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        solver.assemble(coord)
+        e0.record()
+        for _ in range(reps):
+            solver.assemble(coord)
+        e1.record()
+        torch.cuda.synchronize()
+        asm_ms = e0.elapsed_time(e1) / reps
+        asm_bytes = (72.0 * n_atoms * n_atoms + 24.0 * n_atoms) * B
+        asm = asm_bytes / (asm_ms * 1e-3) / 1e9
+        rooflines["assembly"] = {
+            "kernel": "k_hessian", "bound": "hbm", "achieved": round(asm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(asm / HBM_PEAK_GBS, 4), "avg_launch_ms": round(asm_ms, 4),
+            "algorithmic_bytes_per_launch": round(asm_bytes),
+            "what": "72 B per ordered atom pair (9 N^2 f64 written once) + 24 N B read, per structure",
+        }
 
-    if world > 1:
-        dist.barrier()
-
-    if rank == 0:
         total_structures = B * world * args.steps
         value = 3 * n_atoms * total_structures / elapsed
-        cpu = None
+        cpu = gates = None
         if not args.no_cpu_baseline:
-            cpu, w_cpu = cpu_baseline(n_atoms)
-            rel = np.abs(w_gpu0[6:] - w_cpu[6:]) / np.abs(w_cpu[6:])
-            cpu["gpu_vs_cpu_max_rel_eigenvalue_diff"] = float(rel.max())
+            cpu, cpu_h, cpu_pairs, cpu_w = cpu_baseline(n_atoms, "hinsen", runs=args.cpu_runs)
+            gates = parity_gates(sc, solver, coord, w, v, n_atoms, cpu_h, cpu_pairs, cpu_w, torch)
         out = {
             "metric": "ANM modes/sec (Hessian build + full eigensolve), N=2000 C-alpha",
-            "value": round(value, 1),
-            "unit": "modes/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
+            "value": round(value, 1), "unit": "modes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"C3: N={n_atoms} C-alpha ANM, HinsenForceField (no cutoff), full {n}x{n} eigensolve, all modes + vectors",
                 "structures_per_gpu_per_step": B,
                 "solves_per_s": round(total_structures / elapsed, 3),
                 "parallelism": "independent structures sharded over GPUs, no data-path collective",
             },
-            "roofline": roofline,
-            "phases_ms_profiled_step": phases,
-            "cpu_baseline": cpu,
+            "roofline": roofline, "rooflines": rooflines, "phases_ms_profiled_step": phases,
+            "parity_gates": gates, "cpu_baseline": cpu,
         }
+    return out
+
+
+def run_c4(args, rank, world, torch, dist):
+    """BASELINE.json configs[3]: 32 structures of N = 1000 per GPU through solve_sharded (RCCL scatter / gather)."""
+    import springcraft_amd as sc
+    from springcraft_amd.batch import DeviceBatchSolver, shard_bounds, solve_sharded
+
+    n_atoms, per_gpu = 1000, args.structures_per_gpu if args.structures_per_gpu_set else 32
+    total = per_gpu * world
+    ff = sc.InvariantForceField(13.0)
+    coords = synthetic_coords(n_atoms, list(range(total))) if rank == 0 else None
+    lo, hi = shard_bounds(total, world, rank)
+    solver = DeviceBatchSolver(n_atoms, hi - lo, ff, dim=3, want_vectors=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    w = None
+    for _ in range(args.warmup):
+        w, _ = solve_sharded(coords, ff, dim=3, want_vectors=True, solver=solver)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w, _ = solve_sharded(coords, ff, dim=3, want_vectors=True, solver=solver)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # every rank checks its own shard: residual + orthogonality of its first and last structure (device arithmetic)
+    h_all = solver.assemble(solver.last_coord)
+    worst = torch.zeros(2, dtype=torch.float64, device="cuda")
+    eye = torch.eye(3 * n_atoms, dtype=torch.float64, device="cuda")
+    for b in sorted(set([0, hi - lo - 1])):
+        hb, wb, vb = h_all[b], solver.w[b], solver.v[b]
+        r = hb @ vb.T - vb.T * wb[None, :]
+        worst[0] = max(worst[0], torch.linalg.vector_norm(r, dim=0).max() / wb.abs().max())
+        worst[1] = max(worst[1], (vb @ vb.T - eye).abs().max())
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    out = None
+    if rank == 0:
+        cpu = gates = None
+        if not args.no_cpu_baseline:
+            from oracle import enm_oracle as orc
+
+            cpu, _, _, cpu_w = cpu_baseline(n_atoms, "inv13", runs=args.cpu_runs)
+            w0 = w[0]
+            gates = {
+                "eigenvalues_max_rel_diff_nontrivial": float((np.abs(w0[6:] - cpu_w[6:]) / np.abs(cpu_w[6:])).max()),
+                "trivial_modes_max_abs_over_lambda_max": float(np.abs(w0[:6]).max() / np.abs(cpu_w).max()),
+                "residual_max_over_norm_all_ranks": float(worst[0]),
+                "orthogonality_max_all_ranks": float(worst[1]),
+            }
+            # the gathered eigenvalues of the LAST structure come from the last rank: check them against the oracle too
+            hl, _ = orc.compute_hessian(coords[-1], orc.invariant_ff(13.0))
+            wl = np.linalg.eigvalsh(hl)
+            gates["last_structure_eigenvalues_max_rel_diff"] = float((np.abs(w[-1][6:] - wl[6:]) / np.abs(wl[6:])).max())
+            gates["pass"] = bool(gates["eigenvalues_max_rel_diff_nontrivial"] <= 1e-5
+                                 and gates["last_structure_eigenvalues_max_rel_diff"] <= 1e-5
+                                 and gates["residual_max_over_norm_all_ranks"] <= 1e-5
+                                 and gates["orthogonality_max_all_ranks"] <= 1e-8)
+        out = {
+            "metric": "ANM modes/sec, batch of independent N=1000 C-alpha solves sharded over GPUs (config C4)",
+            "value": round(3 * n_atoms * total * args.steps / elapsed, 1), "unit": "modes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"C4: {total} independent N={n_atoms} C-alpha ANM (InvariantForceField 13 A), all modes + vectors, "
+                            f"{per_gpu} per GPU, solve_sharded: RCCL scatter of coordinates + gather of eigenvalues inside the step",
+                "structures_per_gpu_per_step": per_gpu,
+                "solves_per_s": round(total * args.steps / elapsed, 3),
+                "parallelism": "independent structures sharded over GPUs; collectives only for scatter / gather",
+                "backend": dist.get_backend(),
+            },
+            "roofline": None, "parity_gates": gates, "cpu_baseline": cpu,
+        }
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["c3", "c4"], default="c3")
+    ap.add_argument("--structures-per-gpu", type=int, default=None)
+    ap.add_argument("--n-atoms", type=int, default=2000)
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    args.structures_per_gpu_set = args.structures_per_gpu is not None
+    if args.structures_per_gpu is None:
+        args.structures_per_gpu = 64
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))       # decided before anything in this process touches the GPU
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: springcraft_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1 or args.config == "c4":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    out = (run_c4 if args.config == "c4" else run_c3)(args, rank, world, torch, dist)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()   # rank 0 spends ~12 s in the CPU baseline; leave together
+    if dist.is_initialized():
+        dist.barrier()   # rank 0 spends tens of seconds in the CPU baseline; leave together
         dist.destroy_process_group()
+    if rank == 0 and out.get("parity_gates") and not out["parity_gates"]["pass"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

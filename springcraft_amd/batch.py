@@ -88,11 +88,12 @@ class DeviceBatchSolver:
 
     def solve(self, coord):
         """One pass of the hot path over the batch: assembly + full eigensolve, all on device."""
+        self.last_coord = coord
         self.assemble(coord)
         return self.eigh()
 
 
-def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, solver_factory=None):
+def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, solver_factory=None, solver=None):
     """
     Solve ``len(coords)`` independent structures over all ranks of ``group``.
 
@@ -103,7 +104,9 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
 
     Exchange steps (the only communication): scatter of coordinate shards, gather of eigenvalues.
     ``solver_factory(n_atoms, batch)`` may replace the device solver (used by the CPU/gloo tests,
-    which check the sharding and the collectives, not the arithmetic).
+    which check the sharding and the collectives, not the arithmetic).  ``solver``: a
+    :class:`DeviceBatchSolver` built for this rank's shard size, reused across calls (its buffers and
+    the eigensolver workspace are then allocated once).
     """
     import torch
     import torch.distributed as dist
@@ -149,7 +152,11 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
     v_local = None
     if nloc > 0:
         if solver_factory is None:
-            solver = DeviceBatchSolver(n_atoms, nloc, force_field, dim=dim, want_vectors=want_vectors)
+            if solver is None:
+                solver = DeviceBatchSolver(n_atoms, nloc, force_field, dim=dim, want_vectors=want_vectors)
+            elif (solver.n_atoms, solver.batch, solver.dim) != (n_atoms, nloc, dim):
+                raise ValueError(f"solver was built for {(solver.n_atoms, solver.batch, solver.dim)}, "
+                                 f"this rank's shard is {(n_atoms, nloc, dim)}")
             w, v_local = solver.solve(local[:nloc].contiguous())
             w_local[:nloc] = w
         else:

@@ -178,16 +178,18 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
 
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
                      nref, off);
-  SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g));
+  SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g, false, false, kGemmAkBk));
   hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)npanels, (unsigned)batch), dim3(256),
                      sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
-  SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile));
+  SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile, 1, false, false, kGemmAmBk));
 
   for (int p = npanels - 1; p >= 0; --p) {
     const int mrow = n - p * nbt - off;
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s, false, false,
+                           kGemmAkBk));
     hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile));
+    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile, 1, false, false,
+                           kGemmAmBk));
   }
   SC_HIP(ctx, hipGetLastError());
   SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload

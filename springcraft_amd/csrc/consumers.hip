@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_prs_norm(double* __restrict__ m, const 
 
 int run_gemm(sc_ctx* ctx, const GemmDesc& D, GemmDesc* d_desc) {
   SC_HIP(ctx, hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, ctx->stream));
-  return launch_gemm_f64(ctx, d_desc, 1, D.m, D.n, kGemmTile);
+  // both callers: A(i, k) with unit row stride, B(k, j) with unit column stride
+  return launch_gemm_f64(ctx, d_desc, 1, D.m, D.n, kGemmTile, 1, false, false, kGemmAmBn);
 }
 
 }  // namespace

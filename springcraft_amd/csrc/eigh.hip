@@ -403,7 +403,7 @@ int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_
     D.c = d_out; D.ldc = n; D.m = n; D.n = n; D.k = n;
     D.alpha = 1.0; D.beta = 0.0;
     if (hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, st) != hipSuccess) rc = SC_ERR_HIP;
-    if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile);
+    if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile, 1, false, false, kGemmAmBn);
     if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;
   }
   (void)hipFree(d_w); (void)hipFree(d_q); (void)hipFree(d_qs); (void)hipFree(d_desc);

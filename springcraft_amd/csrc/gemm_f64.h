@@ -44,5 +44,10 @@ constexpr int kGemmTile = 3;
 // split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
 // gather: the records carry a_kidx / b_kidx lists (D&C merges); uses the 64x64x8 tile whatever `tile` says.
 // tri: the records carry a_tri masks (lower-stored symmetric A; band reduction); 64x64x8 tile, no gathers.
+// layout: which axis of each operand has stride 1 in ALL records of the launch (the records live in device memory, the
+// host cannot look): kGemmAmBk "NN" (sa_i = 1, sb_k = 1), kGemmAkBk "TN" (sa_k = 1, sb_k = 1), kGemmAmBn "NT"
+// (sa_i = 1, sb_j = 1).  Launches that state it (and carry no gather lists) run the MFMA-paced k_gemm2 with a block
+// tile chosen from the launch size; -1 (unknown) runs the older stride-agnostic kernel with the `tile` asked for.
+constexpr int kGemmAmBk = 0, kGemmAkBk = 1, kGemmAmBn = 2;
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k = 1, bool gather = false, bool tri = false);
+                    int split_k = 1, bool gather = false, bool tri = false, int layout = -1);

@@ -12,7 +12,9 @@
 // The MFMA is fed "swapped" (its A operand comes from the B tile, its B operand from the A tile):
 // the accumulator then holds C^T fragments whose 16 consecutive lanes map to 16 consecutive ROWS
 // of the column-major C, so C loads / stores are 128-byte contiguous segments.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "gemm_f64.h"
@@ -235,29 +237,374 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restri
   }
 }
 
+
+// ================================================================================================================
+// k_gemm2: the MFMA-paced kernel used for every launch without gather lists.
+//
+// The f64 matrix pipe issues one v_mfma_f64_16x16x4_f64 per 64 cycles per SIMD at the 2.4 GHz the chip holds under this
+// load (profiles/r02_probe_clock.txt: 78 TFLOP/s, the datasheet rate), so what a GEMM has to do is keep that pipe
+// issuing: long MFMA runs between barriers and nothing in the loop that can stall it.
+//   * block tile BM x BN (128 x 128, 128 x 64 or 64 x 64), K step BK = 16, 4 waves as 2 x 2: a wave owns (BM/2) x (BN/2),
+//     i.e. up to 4 x 4 MFMA tiles = 16 independent accumulators and 64 MFMAs (4096 pipe cycles) per K step against
+//     8 fragment reads per 16 MFMAs;
+//   * two workgroups per CU (<= 256 VGPRs, <= 74 KB LDS each): the partner's MFMAs fill the barrier / staging gaps;
+//   * operand staging global -> registers -> LDS with ONE register set, written to the other LDS buffer after the MFMA
+//     run of the current K step and re-issued for K step t + 2 right away; the loads are unconditional (clamped
+//     indices) and masked by a select, so the loop holds no branch and no load the compiler must wait for early;
+//   * fragments of k-step k4 + 1 are read while the MFMAs of k4 issue (register double buffer);
+//   * LDS images are conflict-free for both the staging writes and the fragment reads, for either source layout:
+//       source contiguous along the tile's own axis x (m for A, n for B):  [k][X + 16] doubles
+//       source contiguous along k:                                      [k / 2][X + 1][2] doubles
+//   * the MFMA is fed swapped (A operand from the B tile) so that 16 consecutive lanes of an accumulator register are
+//     16 consecutive rows of the column-major C: C loads / stores are 128-byte segments.
+template <int X, bool XCONTIG>
+struct StageImage {
+  // doubles per buffer
+  static constexpr int kSize = XCONTIG ? 16 * (X + 16) : 8 * (X + 1) * 2;
+  __device__ static __forceinline__ int at(int x, int k) {
+    return XCONTIG ? k * (X + 16) + x : ((k >> 1) * (X + 1) + x) * 2 + (k & 1);
+  }
+};
+
+typedef const double __attribute__((address_space(1)))* gptr_c;   // loads through these are global_load, not flat_load
+typedef double __attribute__((address_space(1)))* gptr;             // (a flat access also counts on lgkmcnt: the barrier's wait would wait for it)
+
+template <int BM, int BN, bool AM, bool BNC, bool TRI>
+__global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k) {
+  constexpr int BK = 16;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  using ImgA = StageImage<BM, AM>;
+  using ImgB = StageImage<BN, BNC>;
+  constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sA = smem;                       // [2][ImgA::kSize]
+  double* sB = smem + 2 * ImgA::kSize;     // [2][ImgB::kSize]
+
+  const int z = blockIdx.z;
+  const int slice = split_k > 1 ? z % split_k : 0;
+  const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
+  const int M = D.m, N = D.n, K = D.k;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
+  if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
+
+  int k_begin = 0, k_end = K;
+  if (split_k > 1) {
+    const int chunk = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
+    k_begin = slice * chunk;
+    k_end = min(K, k_begin + chunk);
+  }
+  const int tri = TRI ? D.a_tri : 0;
+  if (TRI && tri == 1) k_end = min(k_end, m0 + BM);
+  if (TRI && tri == 2) k_begin = max(k_begin, m0 / BK * BK);
+
+  const char* Ab = (const char*)D.a;
+  const char* Bb = (const char*)D.b;
+  const long long sa = AM ? D.sa_k : D.sa_i;   // the stride that is not 1
+  const long long sb = BNC ? D.sb_k : D.sb_j;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  // ---- staging maps: element p of this thread is (x, k) of the tile
+  //   x-contiguous source: x = tid % X, k = tid / X + p * (256 / X);   k-contiguous: k = tid % 16, x = tid / 16 + 16 p
+  const int ax = AM ? tid % BM : tid / BK, ak = AM ? tid / BM : tid % BK;
+  const int bx = BNC ? tid % BN : tid / BK, bk = BNC ? tid / BN : tid % BK;
+  constexpr int A_KSTEP = AM ? 256 / BM : 0, A_XSTEP = AM ? 0 : 256 / BK;
+  constexpr int B_KSTEP = BNC ? 256 / BN : 0, B_XSTEP = BNC ? 0 : 256 / BK;
+
+  // Byte offsets that do not change along K (rows / columns clamped into the matrix: what lands in the out-of-range
+  // part of a tile is never stored).  x-contiguous: one offset, element p adds the uniform p * KSTEP * stride;
+  // k-contiguous: element p is row (x0 + 16 p + tid / 16), its offset relative to the uniform row x0 + 16 p.
+  long long a_thr = 0, b_thr = 0;
+  int a_off[AM ? 1 : A_PER], b_off[BNC ? 1 : B_PER];
+  if (AM) a_thr = ((long long)min(m0 + ax, M - 1) + (long long)ak * sa) * 8;
+  else {
+#pragma unroll
+    for (int p = 0; p < A_PER; ++p)
+      a_off[p] = (int)(((long long)(min(m0 + p * A_XSTEP + ax, M - 1) - (m0 + p * A_XSTEP)) * sa + ak) * 8);
+  }
+  if (BNC) b_thr = ((long long)min(n0 + bx, N - 1) + (long long)bk * sb) * 8;
+  else {
+#pragma unroll
+    for (int p = 0; p < B_PER; ++p)
+      b_off[p] = (int)(((long long)(min(n0 + p * B_XSTEP + bx, N - 1) - (n0 + p * B_XSTEP)) * sb + bk) * 8);
+  }
+
+  double ra[A_PER], rb[B_PER];
+  // Raw loads, always in bounds; the masks are applied when the registers go to LDS, one MFMA run later, so that
+  // nothing in between waits for the loads.  Full K steps (no clamp on k): thread base + uniform offsets only.
+  auto g_load = [&](int kt) {
+    if (kt + BK <= K) {
+      if (AM) {
+        const char* t0 = Ab + a_thr + (long long)kt * sa * 8;
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) ra[p] = *(gptr_c)(t0 + (long long)(p * A_KSTEP) * sa * 8);
+      } else {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p)
+          ra[p] = *(gptr_c)(Ab + ((long long)(m0 + p * A_XSTEP) * sa + kt) * 8 + a_off[p]);
+      }
+      if (BNC) {
+        const char* t0 = Bb + b_thr + (long long)kt * sb * 8;
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) rb[p] = *(gptr_c)(t0 + (long long)(p * B_KSTEP) * sb * 8);
+      } else {
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p)
+          rb[p] = *(gptr_c)(Bb + ((long long)(n0 + p * B_XSTEP) * sb + kt) * 8 + b_off[p]);
+      }
+    } else {   // last, partial K step: k clamped as well
+#pragma unroll
+      for (int p = 0; p < A_PER; ++p) {
+        const int x = ax + p * A_XSTEP, k = kt + ak + p * A_KSTEP;
+        const long long gi = min(m0 + x, M - 1), gk = min(k, K - 1);
+        ra[p] = *(gptr_c)(Ab + (AM ? gi + gk * sa : gi * sa + gk) * 8);
+      }
+#pragma unroll
+      for (int p = 0; p < B_PER; ++p) {
+        const int x = bx + p * B_XSTEP, k = kt + bk + p * B_KSTEP;
+        const long long gj = min(n0 + x, N - 1), gk = min(k, K - 1);
+        rb[p] = *(gptr_c)(Bb + (BNC ? gj + gk * sb : gj * sb + gk) * 8);
+      }
+    }
+  };
+  auto s_write = [&](int buf, int kt) {
+    double* a_s = sA + buf * ImgA::kSize;
+    double* b_s = sB + buf * ImgB::kSize;
+    // masks only where the K step leaves [k_begin, k_end) or meets the diagonal of a triangular operand
+    bool mask = kt + BK > k_end || kt < k_begin;
+    if (TRI) mask = mask || (tri == 1 && kt + BK - 1 > m0) || (tri == 2 && kt <= m0 + BM - 1);
+    if (mask) {
+#pragma unroll
+      for (int p = 0; p < A_PER; ++p) {
+        const int x = ax + p * A_XSTEP, k = kt + ak + p * A_KSTEP;
+        bool ok = k < k_end && k >= k_begin;
+        if (TRI) {
+          const int gi = m0 + x;
+          ok = ok && (tri == 0 || (tri == 1 ? gi >= k : k > gi));
+        }
+        a_s[ImgA::at(x, ak + p * A_KSTEP)] = ok ? ra[p] : 0.0;
+      }
+#pragma unroll
+      for (int p = 0; p < B_PER; ++p) {
+        const int k = kt + bk + p * B_KSTEP;
+        b_s[ImgB::at(bx + p * B_XSTEP, bk + p * B_KSTEP)] = (k < k_end && k >= k_begin) ? rb[p] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < A_PER; ++p) a_s[ImgA::at(ax + p * A_XSTEP, ak + p * A_KSTEP)] = ra[p];
+#pragma unroll
+      for (int p = 0; p < B_PER; ++p) b_s[ImgB::at(bx + p * B_XSTEP, bk + p * B_KSTEP)] = rb[p];
+    }
+  };
+
+  d4 acc[NT][MT];
+  // C(row = m0 + wm*WM + mi*16 + fr, col = n0 + wn*WN + ni*16 + fk + 4r) <-> acc[ni][mi][r]
+  gptr C = (gptr)(D.c + (split_k > 1 ? (long long)slice * D.split_stride : 0LL));
+  const double alpha = D.alpha;
+  const double beta = split_k > 1 ? 0.0 : D.beta;
+  const long long ldc = D.ldc;
+  const bool lower = D.lower_only != 0;
+  const int roff = D.row_off, coff = D.col_off;
+
+  // beta * C goes straight into the accumulators (scaled by 1/alpha); its loads fly together with the first tiles
+  const bool with_c = beta != 0.0 && alpha != 0.0;
+  if (with_c) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
+        gptr_c ccol = C + (long long)min(col, N - 1) * ldc;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int row = m0 + wm * WM + mi * 16 + fr;
+          acc[ni][mi][r] = ccol[min(row, M - 1)];
+        }
+      }
+  }
+  if (k_begin < k_end) g_load(k_begin);
+  else {
+#pragma unroll
+    for (int p = 0; p < A_PER; ++p) ra[p] = 0.0;
+#pragma unroll
+    for (int p = 0; p < B_PER; ++p) rb[p] = 0.0;
+  }
+  s_write(0, k_begin);
+  if (k_begin + BK < k_end) g_load(k_begin + BK);
+  if (with_c) {
+    const double scale = beta / alpha;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] *= scale;
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  __syncthreads();
+
+  // K loop.  Iteration t: the registers hold K step t + 1 (loaded one MFMA run ago): write them to the other buffer
+  // (all waves left it at the barrier that ended iteration t - 1), re-issue the loads for K step t + 2, then the MFMA
+  // run of K step t with the fragments of k4 + 1 read while the MFMAs of k4 issue.
+  int buf = 0;
+  for (int kt = k_begin; kt < k_end; kt += BK) {
+    if (kt + BK < k_end) s_write(buf ^ 1, kt + BK);
+    if (kt + 2 * BK < k_end) g_load(kt + 2 * BK);
+    const double* a_s = sA + buf * ImgA::kSize + ImgA::at(wm * WM + fr, fk);
+    const double* b_s = sB + buf * ImgB::kSize + ImgB::at(wn * WN + fr, fk);
+    double af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) af[0][mi] = a_s[ImgA::at(mi * 16, 0)];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) bf[0][ni] = b_s[ImgB::at(ni * 16, 0)];
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) {
+      const int cur = k4 & 1, nxt = cur ^ 1;
+      if (k4 + 1 < BK / 4) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) af[nxt][mi] = a_s[ImgA::at(mi * 16, (k4 + 1) * 4)];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bf[nxt][ni] = b_s[ImgB::at(ni * 16, (k4 + 1) * 4)];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[cur][ni], af[cur][mi], acc[ni][mi], 0, 0, 0);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue (store only)
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
+      if (col >= N) continue;
+      gptr ccol = C + (long long)col * ldc;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int row = m0 + wm * WM + mi * 16 + fr;
+        if (row >= M) continue;
+        if (lower && (row + roff) < (col + coff)) continue;
+        ccol[row] = alpha * acc[ni][mi][r];
+      }
+    }
+  }
+}
+
+// One instantiation per (block tile, layout, triangular A); its dynamic LDS size is raised above the 64 KB default once.
+template <int BM, int BN, bool AM, bool BNC, bool TRI>
+void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k) {
+  constexpr size_t lds = sizeof(double) * 2 * (size_t)(StageImage<BM, AM>::kSize + StageImage<BN, BNC>::kSize);
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI>), grid, dim3(256), lds, st, d_desc, split_k);
+}
+
+template <int BM, int BN, bool TRI>
+void launch_gemm2_layout(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k, int layout) {
+  if (layout == kGemmAmBn) {
+    if constexpr (!TRI) launch_gemm2_inst<BM, BN, true, true, false>(st, grid, d_desc, split_k);
+  } else if (layout == kGemmAmBk) {
+    launch_gemm2_inst<BM, BN, true, false, TRI>(st, grid, d_desc, split_k);
+  } else {
+    // both operands k-contiguous: 128 x 128 would spill (8 + 8 row offsets on top of 128 accumulator registers)
+    if constexpr (!(BM == 128 && BN == 128)) launch_gemm2_inst<BM, BN, false, false, TRI>(st, grid, d_desc, split_k);
+  }
+}
+
+}  // namespace
+
+namespace {
+int g_gemm2_force_tile = 0;   // debugging (sc_dbg_gemm_bench): 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64
+bool gemm2_enabled() {
+  static const bool on = getenv("SPRINGCRAFT_GEMM_OLD") == nullptr;
+  return on;
+}
+// block tile of k_gemm2: 128-wide in a dimension when the problem is at least that wide there and the launch still has
+// >= 2 workgroups per CU (lower-only launches: about half of the square grid does work)
+void gemm2_tile(const sc_ctx* ctx, int count, int max_m, int max_n, int split_k, int layout, int* bm, int* bn) {
+  static const int env_force = [] { const char* e = getenv("SPRINGCRAFT_GEMM2_TILE"); return e ? atoi(e) : 0; }();
+  const int force = g_gemm2_force_tile ? g_gemm2_force_tile : env_force;
+  if (force == 1 && layout != kGemmAkBk) { *bm = 128; *bn = 128; return; }
+  if (force == 1) { *bm = 128; *bn = 64; return; }
+  if (force == 2) { *bm = 128; *bn = 64; return; }
+  if (force == 3) { *bm = 64; *bn = 64; return; }
+  const long long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  auto blocks = [&](int a, int b) {
+    return (long long)((max_m + a - 1) / a) * ((max_n + b - 1) / b) * count * split_k;
+  };
+  *bm = 64; *bn = 64;
+  if (max_m > 64 && blocks(128, 64) >= 2 * cus) *bm = 128;
+  if (*bm == 128 && max_n > 64 && layout != kGemmAkBk && blocks(128, 128) >= 3 * cus) *bn = 128;
+}
 }  // namespace
 
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k, bool gather, bool tri) {
+                    int split_k, bool gather, bool tri, int layout) {
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
+  hipStream_t st = ctx->stream;
+  if (!gather && layout >= 0 && layout <= 2 && !(tri && layout == kGemmAmBn) && gemm2_enabled()) {
+    int bm, bn;
+    gemm2_tile(ctx, count, max_m, max_n, split_k, layout, &bm, &bn);
+    const long long gz = (long long)count * split_k;
+    if (gz > 65535) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "GEMM launch with %lld records x slices (max 65535)", gz);
+    dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)gz);
+    if (bm == 128 && bn == 128) {
+      if (tri) launch_gemm2_layout<128, 128, true>(st, grid, d_desc, split_k, layout);
+      else launch_gemm2_layout<128, 128, false>(st, grid, d_desc, split_k, layout);
+    } else if (bm == 128) {
+      if (tri) launch_gemm2_layout<128, 64, true>(st, grid, d_desc, split_k, layout);
+      else launch_gemm2_layout<128, 64, false>(st, grid, d_desc, split_k, layout);
+    } else {
+      if (tri) launch_gemm2_layout<64, 64, true>(st, grid, d_desc, split_k, layout);
+      else launch_gemm2_layout<64, 64, false>(st, grid, d_desc, split_k, layout);
+    }
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+  }
+  // gather / tri launches always run the 64 x 64 x 8 instantiation: size the grid and the LDS for that tile
+  if (gather || tri) tile = 3;
   const int bm = tile == 0 ? 128 : 64;
   const int bn = (tile == 2 || tile == 3) ? 64 : 128;
   const int bk = tile == 3 ? 8 : 16;
-  dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(count * split_k));
+  // grid.z is limited to 65535: launch in chunks of records
+  const int max_rec = 65535 / split_k;
+  if (max_rec < 1) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "split_k %d too large", split_k);
   const size_t lds = sizeof(double) * 2 * bk * ((size_t)(bm + PAD) + (bn + PAD));
-  if (tri)      // triangular A operands: default tile only
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false, true>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
-  else if (gather)   // only the default tile is instantiated with gather support
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, true>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
-  else if (tile == 1)
-    hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
-  else if (tile == 2)
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
-  else if (tile == 3)
-    hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
-  else
-    hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2, false>), grid, dim3(256), lds, ctx->stream, d_desc, split_k);
+  for (int r0 = 0; r0 < count; r0 += max_rec) {
+    const int cnt = std::min(max_rec, count - r0);
+    const GemmDesc* dd = d_desc + r0;
+    dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(cnt * split_k));
+    if (tri)
+      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false, true>), grid, dim3(256), lds, st, dd, split_k);
+    else if (gather)
+      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, true>), grid, dim3(256), lds, st, dd, split_k);
+    else if (tile == 1)
+      hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2, false>), grid, dim3(256), lds, st, dd, split_k);
+    else if (tile == 2)
+      hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4, false>), grid, dim3(256), lds, st, dd, split_k);
+    else if (tile == 3)
+      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false>), grid, dim3(256), lds, st, dd, split_k);
+    else
+      hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2, false>), grid, dim3(256), lds, st, dd, split_k);
+  }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -293,7 +640,10 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   if (mode == 2) { D.sa_i = k; D.sa_k = 1; D.sb_k = 1; D.sb_j = k; }
   D.split_stride = (long long)m * n;
   SC_HIP(ctx, hipMemcpy(dd, &D, sizeof(D), hipMemcpyHostToDevice));
-  SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k));
+  // tile 10 .. 13: k_gemm2 (10: automatic block tile, 11: 128 x 128, 12: 128 x 64, 13: 64 x 64); else the old kernel
+  const int layout = tile >= 10 ? (mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk)) : -1;
+  g_gemm2_force_tile = tile >= 10 ? tile - 10 : 0;
+  SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout));
   SC_HIP(ctx, hipStreamSynchronize(st));
   // spot check 64 entries against a host dot product (beta path: C was 0 before the first launch)
   SC_HIP(ctx, hipMemcpy(hc.data(), c, ec * 8, hipMemcpyDeviceToHost));
@@ -316,12 +666,13 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   SC_HIP(ctx, hipEventCreate(&e0));
   SC_HIP(ctx, hipEventCreate(&e1));
   SC_HIP(ctx, hipEventRecord(e0, st));
-  for (int it = 0; it < iters; ++it) SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k));
+  for (int it = 0; it < iters; ++it) SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout));
   SC_HIP(ctx, hipEventRecord(e1, st));
   SC_HIP(ctx, hipEventSynchronize(e1));
   float ms = 0.f;
   SC_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
   if (ms_out) *ms_out = ms / iters;
+  g_gemm2_force_tile = 0;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(dd);
   return SC_OK;

@@ -580,7 +580,8 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
       }
       const int mt = n - pend;
       if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-      SC_TRY(launch_gemm_f64(ctx, d_syr2k_descs + (size_t)panel * batch, batch, mt, mt, kGemmTile));
+      SC_TRY(launch_gemm_f64(ctx, d_syr2k_descs + (size_t)panel * batch, batch, mt, mt, kGemmTile, 1, false, false,
+                             kGemmAmBn));
       if (prof) {
         SC_HIP(ctx, hipEventRecord(ev[3], st));
         SC_HIP(ctx, hipEventSynchronize(ev[3]));

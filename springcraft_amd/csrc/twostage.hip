@@ -1085,11 +1085,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                            kB);
     }
     const GemmDesc* g = d_descs + (size_t)p * 6 * batch;
-    SC_TRY(launch_gemm_f64(ctx, g, 2 * batch, m, kB, kGemmTile, 1, false, true));
-    SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit));
+    SC_TRY(launch_gemm_f64(ctx, g, batch, m, kB, kGemmTile, 1, false, true, kGemmAmBk));           // X1 = L V
+    SC_TRY(launch_gemm_f64(ctx, g + batch, batch, m, kB, kGemmTile, 1, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+    SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
     hipLaunchKernelGGL(k_sb_small, dim3((unsigned)batch), dim3(256), lds_small, st, d_tri_ws, TL, d_sb_ws, SL, j0);
-    SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile));
-    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile));
+    SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile, 1, false, false, kGemmAmBn));
   }
   SC_HIP(ctx, hipGetLastError());
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
