@@ -390,18 +390,16 @@ int sc_pairs(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
   double* d_sq = sq_dist ? bump.take<double>((size_t)capacity + 1) : nullptr;
   const PatchDev* pdev = st.has_patch ? &st.patch : nullptr;
   SC_TRY(launch_contact_counts(ctx, st.d_coord, n, st.ff_dev, pdev, d_counts));
-  std::vector<int64_t> h((size_t)n + 1);
-  SC_HIP(ctx, hipMemcpyAsync(h.data() + 1, d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  // offsets of the rows in the ordered pair list: exclusive scan on the device, only the total comes back
+  SC_TRY(launch_exclusive_scan_i64(ctx, d_counts, n, d_off));
+  int64_t k = 0;
+  SC_HIP(ctx, hipMemcpyAsync(&k, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  h[0] = 0;
-  for (int64_t i = 0; i < n; ++i) h[(size_t)i + 1] += h[(size_t)i];
-  const int64_t k = h[(size_t)n];
   if (n_pairs) *n_pairs = k;
   if (k > capacity)
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pair buffer too small: %lld > %lld", (long long)k,
                         (long long)capacity);
   if (k == 0) return SC_OK;
-  SC_HIP(ctx, hipMemcpyAsync(d_off, h.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   SC_TRY(launch_pair_fill(ctx, st.d_coord, n, st.ff_dev, pdev, d_off, d_pairs, d_sq));
   SC_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, (size_t)k * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (sq_dist)

@@ -451,6 +451,41 @@ int launch_hessian(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
   return SC_OK;
 }
 
+// Exclusive prefix sum of n int64 counts into n + 1 offsets (out[0] = 0, out[n] = total): one workgroup, every thread
+// owns a contiguous chunk, chunk sums scanned with wave shuffles (the offsets of the ordered pair list, np.where order).
+__global__ __launch_bounds__(1024) void k_exclusive_scan_i64(const long long* __restrict__ in, long long n,
+                                                             long long* __restrict__ out) {
+  __shared__ long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long per = (n + 1023) / 1024;
+  const long long lo = (long long)tid * per, hi = lo + per < n ? lo + per : n;
+  long long s = 0;
+  for (long long i = lo; i < hi; ++i) s += in[i];
+  long long incl = s;   // inclusive scan of the chunk sums inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  long long base = 0;
+  for (int i = 0; i < w; ++i) base += wsum[i];
+  long long run = base + incl - s;
+  for (long long i = lo; i < hi; ++i) {
+    out[i] = run;
+    run += in[i];
+  }
+  if (tid == 1023) out[n] = base + incl;
+}
+
+int launch_exclusive_scan_i64(sc_ctx* ctx, const int64_t* d_in, int64_t n, int64_t* d_out) {
+  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(1024), 0, ctx->stream, (const long long*)d_in, (long long)n,
+                     (long long*)d_out);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
 int launch_pair_fill(sc_ctx* ctx, const double* d_coord, int64_t n, const sc_ff_desc& ff,
                      const PatchDev* patch, const int64_t* d_offsets, int64_t* d_pairs,
                      double* d_sqdist) {

@@ -918,10 +918,367 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
   }
 }
 
+
+// ================================================================================================================
+// Z <- Q2 Z, second generation (k_dia_tfactor2 + k_bt2_apply; tools/models/bt2_model.py is their NumPy specification).
+//
+// The f64 matrix pipe issues one 16x16x4 MFMA per 64 cycles (profiles/r02_probe_clock.txt); k_bt2_fused kept it 43 % busy
+// because every wave fetched its own B operands from L2 (52 doubles per lane and diamond for 184 MFMAs).  Here
+//   * the 128-row window of Z lives in the accumulators as Z itself (rows x columns), split over the waves by COLUMNS:
+//     a wave owns 16 columns x 128 rows = 8 accumulator tiles.  An accumulator register of this MFMA has exactly the lane
+//     layout of a B operand (k = lane >> 4 <-> tile row 4 r + k, j = lane & 15), so  W1 = V^T Z  takes its B operands
+//     straight from the window registers and  Z -= (V T) W1  takes them straight from the W1 accumulators: no LDS
+//     round trip for Z or W1, no synchronisation between the two products;
+//   * the A operands (V^T and -(V T)) are the same for every wave and every column chunk: k_dia_tfactor2 writes them
+//     once per diamond as ready-made MFMA fragments (512 B = one wave-wide ds_read_b64 each) in the order the products
+//     consume them, structural zeros skipped: 80 fragments for V^T (sweep tile st meets row tiles st .. st + 4 only) and
+//     104 for -(V T) (row tile rt meets sweep tiles >= rt - 4 only) = 92 KB per diamond;
+//   * a workgroup of NW = 8 waves (128 columns) streams the fragments of the next product into LDS with LDS-DMA
+//     (global_load_lds_dwordx4, no staging registers) while the current product runs: region A (V^T fragments) is refilled
+//     during product 2, region B during product 1; two barriers per diamond.  A diamond is read from L2 / HBM once per
+//     128 columns instead of once per 32.
+constexpr int kF1 = 80, kF2 = 104;                 // fragments per diamond: product 1 / product 2
+constexpr int kFragDoubles = (kF1 + kF2) * 64;     // 11776 doubles = 92 KB
+// product 1, issue order (rt, r, st): Z tile rt register r is the B operand; sweep tiles st = max(0, rt - 4) .. min(3, rt)
+__host__ __device__ constexpr int p1_stlo(int rt) { return rt > 4 ? rt - 4 : 0; }
+__host__ __device__ constexpr int p1_sthi(int rt) { return rt < 3 ? rt : 3; }
+__host__ __device__ constexpr int p1_cnt(int rt) { return p1_sthi(rt) - p1_stlo(rt) + 1; }
+__host__ __device__ constexpr int p1_base(int rt) {
+  int b = 0;
+  for (int t = 0; t < rt; ++t) b += 4 * p1_cnt(t);
+  return b;
+}
+__host__ __device__ constexpr int p1_index(int rt, int r, int st) { return p1_base(rt) + r * p1_cnt(rt) + (st - p1_stlo(rt)); }
+// product 2, issue order (st, r, rt): W1 tile st register r is the B operand; row tiles rt = 0 .. 4 + st
+__host__ __device__ constexpr int p2_base(int st) { return 4 * (5 * st + st * (st - 1) / 2); }
+__host__ __device__ constexpr int p2_index(int st, int r, int rt) { return p2_base(st) + r * (5 + st) + rt; }
+static_assert(p1_base(8) == kF1 && p2_base(4) == kF2, "fragment counts");
+// fragment index = issue index; the inverse maps (constant-folded in the unrolled products)
+struct P1Step { int rt, r, st; };
+__host__ __device__ constexpr P1Step p1_decode(int f) {
+  int rt = 0;
+  while (rt < 7 && f >= p1_base(rt + 1)) ++rt;
+  const int rem = f - p1_base(rt), cnt = p1_cnt(rt);
+  return P1Step{rt, rem / cnt, p1_stlo(rt) + rem % cnt};
+}
+struct P2Step { int st, r, rt; };
+__host__ __device__ constexpr P2Step p2_decode(int f) {
+  int st = 0;
+  while (st < 3 && f >= p2_base(st + 1)) ++st;
+  const int rem = f - p2_base(st);
+  return P2Step{st, rem / (5 + st), rem % (5 + st)};
+}
+static_assert(p1_index(p1_decode(37).rt, p1_decode(37).r, p1_decode(37).st) == 37, "p1 decode");
+static_assert(p2_index(p2_decode(71).st, p2_decode(71).r, p2_decode(71).rt) == 71, "p2 decode");
+
+typedef const double __attribute__((address_space(1)))* zptr_c;   // global_load / global_store, never flat
+typedef double __attribute__((address_space(1)))* zptr;
+typedef const void __attribute__((address_space(1)))* gvoid_c;
+typedef void __attribute__((address_space(3)))* lvoid;
+
+// acc += A B over k-steps [k4_lo, k4_hi): lane (fr, fk) supplies A[i = fr][k = 4 k4 + fk] = a(fr, k) and
+// B[k][j = fr] = b(k, fr); acc[r] is D[i = 4 r + fk][j = fr].
+template <class FA, class FB>
+__device__ __forceinline__ d4 mma_range(d4 acc, int k4_lo, int k4_hi, int fr, int fk, FA a, FB b) {
+  for (int k4 = k4_lo; k4 < k4_hi; ++k4) {
+    const int k = 4 * k4 + fk;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(fr, k), b(k, fr), acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Per diamond: T = (diag(1 / tau) + striu(V^T V))^-1 (the dlarft recurrence is the back substitution for this inverse;
+// reflectors with tau = 0 are decoupled), then the fragments of V^T and -(V T)^T.  All products on the matrix cores:
+//   Gram (upper tiles, rows where both reflector groups are non-zero), the inverse blocked 16 -> 32 -> 64
+//   (diagonal 16 x 16 blocks by back substitution, one column per lane; off-diagonal blocks X12 = -X11 U12 X22),
+//   and (V T)^T tile by tile - computed transposed because an accumulator register of the transposed tile IS the
+//   fragment (same lane, same order), so it is stored with one coalesced 512-byte write.
+__global__ __launch_bounds__(256) void k_dia_tfactor2(double* __restrict__ sb_all, SbLayout SL, int dia0) {
+  constexpr int LD = kG + 1;
+  __shared__ double Vc[kG * LD];     // Vc[c * LD + i] = V[c + i, c]
+  __shared__ double Us[kG * LD];     // U[a * LD + b]
+  __shared__ double Ts[kG * LD];     // T[a * LD + b]
+  __shared__ double Ps[32 * 33];
+  __shared__ double tau_s[kG];
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const size_t dia = (size_t)dia0 + blockIdx.x;
+  const double* vd = sb + SL.vd + dia * kDiaSize;
+  const double* tau = sb + SL.tau2 + dia * kG;
+  double* frag = sb + SL.frag + dia * kFragDoubles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  {
+    const int c = tid & 63, q = tid >> 6;   // lanes along the sweeps (contiguous in memory)
+    for (int i = q; i < kB; i += 4) Vc[c * LD + i] = vd[(size_t)(c + i) * kG + c];
+    if (tid < kG) tau_s[tid] = tau[tid];
+    for (int idx = tid; idx < kG * LD; idx += 256) { Us[idx] = 0.0; Ts[idx] = 0.0; }
+  }
+  __syncthreads();
+  auto V = [&](int row, int c) -> double {
+    const int i = row - c;
+    return (unsigned)i < (unsigned)kB ? Vc[c * LD + i] : 0.0;
+  };
+  // ---- U: strictly upper part of the Gram matrix, 1 / tau on the diagonal
+  for (int t = w; t < 10; t += 4) {
+    const int ta = t < 4 ? 0 : (t < 7 ? 1 : (t < 9 ? 2 : 3));
+    const int tb = t < 4 ? t : (t < 7 ? t - 3 : (t < 9 ? t - 5 : 3));
+    d4 g = mma_range(d4{0, 0, 0, 0}, 4 * tb, 4 * ta + 20, fr, fk,
+                     [&](int i, int k) { return V(k, 16 * ta + i); }, [&](int k, int j) { return V(k, 16 * tb + j); });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * ta + 4 * r + fk, b = 16 * tb + fr;
+      if (a < b) Us[a * LD + b] = (tau_s[a] != 0.0 && tau_s[b] != 0.0) ? g[r] : 0.0;
+    }
+  }
+  if (tid < kG) Us[tid * LD + tid] = tau_s[tid] != 0.0 ? 1.0 / tau_s[tid] : 1.0;
+  __syncthreads();
+  // ---- diagonal blocks: lane (b, j) solves U_bb x = e_j
+  if (w == 0) {
+    const int b = lane >> 4, j = lane & 15;
+    const double* Ub = Us + (16 * b) * LD + 16 * b;
+    double x[16];
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double s = i == j ? 1.0 : 0.0;
+#pragma unroll
+      for (int l = i + 1; l < 16; ++l) s -= Ub[i * LD + l] * x[l];
+      x[i] = i <= j ? s / Ub[i * LD + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ts[(16 * b + i) * LD + 16 * b + j] = x[i];
+  }
+  __syncthreads();
+  // ---- level 1: blocks (0,1) and (2,3):  X = -T_aa (U_ac T_cc)
+  if (w < 2) {
+    const int lo = 32 * w;
+    d4 p = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Us[(lo + i) * LD + lo + 16 + k]; },
+                     [&](int k, int j) { return Ts[(lo + 16 + k) * LD + lo + 16 + j]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ps[(16 * w + 4 * r + fk) * 33 + fr] = p[r];
+  }
+  __syncthreads();
+  if (w < 2) {
+    const int lo = 32 * w;
+    d4 x = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Ts[(lo + i) * LD + lo + k]; },
+                     [&](int k, int j) { return Ps[(16 * w + k) * 33 + j]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(lo + 4 * r + fk) * LD + lo + 16 + fr] = -x[r];
+  }
+  __syncthreads();
+  // ---- level 2: the 32 x 32 block (rows 0..31, columns 32..63), one 16 x 16 tile per wave
+  {
+    const int ti = w & 1, tj = w >> 1;
+    d4 p = mma_range(d4{0, 0, 0, 0}, 0, 8, fr, fk, [&](int i, int k) { return Us[(16 * ti + i) * LD + 32 + k]; },
+                     [&](int k, int j) { return Ts[(32 + k) * LD + 32 + 16 * tj + j]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ps[(16 * ti + 4 * r + fk) * 33 + 16 * tj + fr] = p[r];
+    __syncthreads();
+    d4 x = mma_range(d4{0, 0, 0, 0}, 0, 8, fr, fk, [&](int i, int k) { return Ts[(16 * ti + i) * LD + k]; },
+                     [&](int k, int j) { return Ps[k * 33 + 16 * tj + j]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(16 * ti + 4 * r + fk) * LD + 32 + 16 * tj + fr] = -x[r];
+  }
+  __syncthreads();
+  if (tid < kG && tau_s[tid] == 0.0) Ts[tid * LD + tid] = 0.0;
+  __syncthreads();
+  // ---- fragments of V^T: frag1[f][l] = V[16 rt + 4 r + (l >> 4)][16 st + (l & 15)]
+  for (int idx = tid; idx < kF1 * 64; idx += 256) {
+    const int f = idx >> 6, l = idx & 63;
+    const P1Step d = p1_decode(f);
+    frag[idx] = V(16 * d.rt + 4 * d.r + (l >> 4), 16 * d.st + (l & 15));
+  }
+  // ---- fragments of -(V T): tile (st, rt) transposed,  D'[sweep i][row j] = sum_l T[l][16 st + i] V[16 rt + j][l]
+  double* frag2 = frag + kF1 * 64;
+  for (int q = w; q < 26; q += 4) {
+    const int st = q < 5 ? 0 : (q < 11 ? 1 : (q < 18 ? 2 : 3));
+    const int rt = q - (st == 0 ? 0 : (st == 1 ? 5 : (st == 2 ? 11 : 18)));
+    const int k4_lo = 4 * rt > 16 ? 4 * rt - 16 : 0;
+    const int k4_hi = 4 * st + 4 < 4 * rt + 4 ? 4 * st + 4 : 4 * rt + 4;
+    d4 d = mma_range(d4{0, 0, 0, 0}, k4_lo, k4_hi, fr, fk, [&](int i, int k) { return Ts[k * LD + 16 * st + i]; },
+                     [&](int k, int j) { return V(16 * rt + j, k); });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) frag2[(size_t)p2_index(st, r, rt) * 64 + lane] = -d[r];
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restrict__ sb_all, SbLayout SL,
+                                                          const int* __restrict__ dia_off, double* __restrict__ z_all,
+                                                          long long stride_z, int ncols, int batch, int xcd_map) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [kF1 * 64] region A | [kF2 * 64] region B
+  const int n = SL.n;
+  constexpr int kCols = 16 * NW;
+  int mat, chunk;
+  if (xcd_map) {   // all column chunks of a matrix on one XCD (see k_bt2_fused)
+    const int nchunk = (ncols + kCols - 1) / kCols;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    mat = xcd + 8 * (slot / nchunk);
+    chunk = slot % nchunk;
+    if (mat >= batch) return;
+  } else {
+    mat = blockIdx.y;
+    chunk = blockIdx.x;
+  }
+  const double* sb = sb_all + (size_t)mat * SL.slab;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int col = chunk * kCols + 16 * w + fr;
+  const bool col_ok = col < ncols;
+  // this lane's column of Z, rows offset by fk: element (tile row 4 r + fk) of a tile starting at row0 is zc[row0 + 4 r]
+  zptr zc = (zptr)(z_all + (size_t)mat * stride_z + (size_t)(col_ok ? col : ncols - 1) * n);
+  const double* ldsA = lds + lane;
+  const double* ldsB = lds + kF1 * 64 + lane;
+
+  // (the mask is applied by a multiplication: a select lets hipcc sink the load under a branch and wait for each one;
+  //  Z holds finite numbers and the clamped address is inside the matrix)
+  const double col_mask = col_ok ? 1.0 : 0.0;
+  auto load_tile = [&](d4& t, int row0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * r + fk;
+      const double v = zc[row < n ? row : n - 1];
+      t[r] = v * (row < n ? col_mask : 0.0);
+    }
+  };
+  auto store_tile = [&](const d4& t, int row0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * r + fk;
+      if (row < n && col_ok) zc[row] = t[r];
+    }
+  };
+  // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a fragment block; the waves share the instructions.
+  // Issued from inline asm: hipcc then keeps no scoreboard entry for them (with the builtin it guards later LDS reads
+  // and register reuse with vmcnt(0), i.e. waits for the DMA it has just issued); their completion is counted by hand:
+  // every wait for them below is an explicit vmcnt(0).  M0 (the LDS destination base) is saved and restored.
+  const unsigned lds_base = (unsigned)(size_t)(lvoid)lds;
+  auto dma = [&](const double* src, int lds_off_doubles, int n_instr) {
+    const char* g = (const char*)src + lane * 16;
+    const unsigned l = lds_base + (unsigned)lds_off_doubles * 8u;
+    for (int q = w; q < n_instr; q += NW) {
+      unsigned keep;
+      const char* gq = g + q * 1024;
+      const unsigned lq = __builtin_amdgcn_readfirstlane(l + (unsigned)q * 1024u);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(gq), "s"(lq)
+                   : "memory");
+    }
+  };
+  auto wait_vm0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  d4 zt[8];
+  for (int S = SL.ngroups - 1; S >= 0; --S) {
+    const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
+    int win = S * kG + 1;
+    const double* fcur = sb + SL.frag + (size_t)d0 * kFragDoubles;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) load_tile(zt[rt], win + 16 * rt);
+    barrier();                       // the previous group's last product 2 has left region A's neighbours alone; A is free
+    dma(fcur, 0, kF1 / 2);
+    wait_vm0();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < nk; ++k, fcur += kFragDoubles) {
+      barrier();                     // X1: region A (diamond k) complete in LDS; every wave is done with region B
+      // ---- W1 = V^T Z
+      // (fragments in groups of 8: the next group is read from LDS while the MFMAs of the current one issue)
+      d4 w1[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+      {
+        double fa[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[0][j] = ldsA[j * 64];
+#pragma unroll
+        for (int g = 0; g < kF1 / 8; ++g) {
+          if (g + 1 < kF1 / 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsA[((g + 1) * 8 + j) * 64];
+          }
+          // region B's DMA goes out behind the first fragment groups, when the stores of the last slide have drained
+          // (hipcc makes the reuse of their registers wait for them) and still 56 MFMAs before the data is needed
+          if (g == 3) dma(fcur + kF1 * 64, kF1 * 64, kF2 / 2);
+          __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g + 1 in front of the MFMAs of group g
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const P1Step d = p1_decode(g * 8 + j);
+            w1[d.st] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[g & 1][j], zt[d.rt][d.r], w1[d.st], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      wait_vm0();
+      barrier();                     // X2: region B complete; every wave is done with region A
+      const bool more = k + 1 < nk;
+      d4 zn[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+      // ---- Z -= (V T) W1
+      {
+        double fb[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[0][j] = ldsB[j * 64];
+#pragma unroll
+        for (int g = 0; g < kF2 / 8; ++g) {
+          if (g + 1 < kF2 / 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[(g + 1) & 1][j] = ldsB[((g + 1) * 8 + j) * 64];
+          }
+          if (g == 2 && more) {
+            dma(fcur + kFragDoubles, 0, kF1 / 2);   // region A of the next diamond
+            // the 64 rows that enter the window next are not touched by this diamond: fetch them behind the MFMAs
+            // (raw: with an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of a loaded value; masked at the slide)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = win + 128 + 16 * t + 4 * r + fk;
+                zn[t][r] = zc[row < n ? row : n - 1];
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const P2Step d = p2_decode(g * 8 + j);
+            zt[d.rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[g & 1][j], w1[d.st][d.r], zt[d.rt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- slide by 64 rows
+      if (more) {
+        wait_vm0();                  // next diamond's region A part of this wave + the new rows (issued a product ago)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_tile(zt[t], win + 16 * t);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          zt[t] = zt[t + 4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zt[t + 4][r] = zn[t][r] * (win + 128 + 16 * t + 4 * r + fk < n ? col_mask : 0.0);
+        }
+        win += 64;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) store_tile(zt[t], win + 16 * t);
+      }
+      // nothing of the slide (the masking of the new rows is the first use of their loads) may sink into the next
+      // diamond: behind its LDS-DMA issue the compiler would wait vmcnt(0) for it
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================================
 // Layout
+// SPRINGCRAFT_BT2_OLD=1: the first-generation stage-2 back-transformation (k_dia_tfactor + k_bt2_fused), kept for A/B runs
+static bool bt2_old_path() {
+  static const bool old = getenv("SPRINGCRAFT_BT2_OLD") != nullptr;
+  return old;
+}
+
 size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   SbLayout L{};
   L.n = n;
@@ -947,7 +1304,8 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   }
   L.ndia = ndia;
   L.vd = take(ndia * kDiaSize);
-  L.vt2 = take(ndia * kDiaSize);
+  if (bt2_old_path()) L.vt2 = take(ndia * kDiaSize);
+  else L.frag = take(ndia * kFragDoubles);
   L.tau2 = take(ndia * kG);
   (void)ncols;
   L.slab = off;
@@ -1131,7 +1489,10 @@ int bt2_prepare(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
   if (n < 3 || SL.ndia == 0) return SC_OK;
   for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
     const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
-    hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
+    if (bt2_old_path())
+      hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
+    else
+      hipLaunchKernelGGL(k_dia_tfactor2, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
   }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
@@ -1148,14 +1509,40 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
-  const int nchunk = (ncols + kNc - 1) / kNc;
-  if (batch >= 8) {
-    const int per_xcd = (batch + 7) / 8;   // matrices per XCD
-    hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)(8 * per_xcd * nchunk)), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
-                       d_z, stride_z, ncols, batch, 1);
+  if (bt2_old_path()) {
+    const int nchunk = (ncols + kNc - 1) / kNc;
+    if (batch >= 8) {
+      const int per_xcd = (batch + 7) / 8;   // matrices per XCD
+      hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)(8 * per_xcd * nchunk)), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
+                         d_z, stride_z, ncols, batch, 1);
+    } else {
+      hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)nchunk, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
+                         d_z, stride_z, ncols, batch, 0);
+    }
   } else {
-    hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)nchunk, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
-                       d_z, stride_z, ncols, batch, 0);
+    // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
+    const size_t lds = sizeof(double) * kFragDoubles;
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * kFragDoubles));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * kFragDoubles));
+      return true;
+    }();
+    (void)attr_set;
+    static const int force_nw = [] { const char* e = getenv("SPRINGCRAFT_BT2_NW"); return e ? atoi(e) : 0; }();
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    int nw = ((long long)((ncols + 127) / 128) * batch >= cus) ? 8 : 4;
+    if (force_nw == 4 || force_nw == 8) nw = force_nw;
+    const int nchunk = (ncols + 16 * nw - 1) / (16 * nw);
+    const bool xcd = batch >= 8;
+    const dim3 grid = xcd ? dim3((unsigned)(8 * ((batch + 7) / 8) * nchunk)) : dim3((unsigned)nchunk, (unsigned)batch);
+    if (nw == 8)
+      hipLaunchKernelGGL(k_bt2_apply<8>, grid, dim3(512), lds, st, d_sb_ws, SL, d_dia_off, d_z, stride_z, ncols, batch,
+                         xcd ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_bt2_apply<4>, grid, dim3(256), lds, st, d_sb_ws, SL, d_dia_off, d_z, stride_z, ncols, batch,
+                         xcd ? 1 : 0);
   }
   SC_HIP(ctx, hipGetLastError());
   if (prof) {
