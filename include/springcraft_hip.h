@@ -214,6 +214,11 @@ int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors);
  *                                 out[5]=the fused stage-2 back-transformation kernel alone. */
 int sc_ctx_set_profiling(sc_ctx* ctx, int enabled);
 int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
+/* Summed device time (ms) of one kernel group of the most recent profiled eigensolve, by name.  Two-stage path:
+ * "panel_qr", "symm" (X = A22 V), "syr2k" (trailing update), "bulge", "dia_tfactor", "dc" (tridiagonal divide & conquer),
+ * "dc_gemm" (its merge GEMMs), "bt2" (stage-2 back-transformation), "bt1_w" / "bt1_update" (the two GEMMs of the stage-1
+ * back-transformation).  Unknown names (or phases the last solve did not run): SC_ERR_INVALID_ARG, *ms = 0. */
+int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
 
 /* ---- device-resident eigenpairs and their consumers ----------------------------------
  * An sc_modes object holds all n eigenvalues and eigenvectors of one model's Kirchhoff (dim 1) or Hessian

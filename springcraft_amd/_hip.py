@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
     "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
     "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
-    "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage",
+    "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage", "sc_last_eigh_phase_ms",
 ]
 
 
@@ -161,6 +161,7 @@ def lib():
         "sc_ctx_set_profiling": (i32, [vp, i32]),
         "sc_ctx_set_two_stage": (i32, [vp, i32]),
         "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
+        "sc_last_eigh_phase_ms": (i32, [vp, C.c_char_p, P(dbl)]),
         "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
         "sc_modes_from_matrix": (i32, [vp, vp, i64, i32, P(vp)]),
         "sc_modes_destroy": (None, [vp]),

@@ -23,6 +23,69 @@ _RESIDUE_MASS = {
 }
 
 
+class _ModesCache:
+    """
+    Byte-bounded LRU over the device-resident eigenpairs (``_hip.Modes``) of model objects.  A ``Modes`` holds the
+    full (n, n) eigenvector matrix in HBM (288 MB for N = 2000 C-alpha); without a bound, a loop that keeps its
+    models alive (``for m in models: m.eigen()``) would pin one per model.  The budget is
+    ``SPRINGCRAFT_MODES_CACHE_BYTES`` (default 2 GiB); the least recently used entries are released first, an
+    entry larger than the whole budget is not kept at all.  The reference caches nothing here (every consumer
+    solves again, nma.py:61): dropping an entry only costs the next consumer call of that model a new solve.
+    """
+
+    def __init__(self):
+        import collections
+        import os
+
+        self.budget = int(os.environ.get("SPRINGCRAFT_MODES_CACHE_BYTES", 2 << 30))
+        self._entries = collections.OrderedDict()   # id(model) -> (weakref to the model, Modes, bytes)
+
+    @staticmethod
+    def _nbytes(modes):
+        return 8 * (modes.order * modes.order + modes.order)
+
+    def get(self, model):
+        e = self._entries.get(id(model))
+        if e is None or e[0]() is not model:
+            return None
+        self._entries.move_to_end(id(model))
+        return e[1]
+
+    def put(self, model, modes):
+        import weakref
+
+        self.drop(model)
+        size = self._nbytes(modes)
+        if size > self.budget:
+            return False
+        self._entries[id(model)] = (weakref.ref(model), modes, size)
+        self._evict()
+        return True
+
+    def drop(self, model):
+        e = self._entries.pop(id(model), None)
+        if e is not None:
+            e[1].close()
+
+    def _evict(self):
+        total = sum(e[2] for e in self._entries.values())
+        while total > self.budget and len(self._entries) > 1:
+            _, (_, modes, size) = self._entries.popitem(last=False)
+            modes.close()
+            total -= size
+
+    def clear(self):
+        while self._entries:
+            _, (_, modes, _) = self._entries.popitem()
+            modes.close()
+
+    def nbytes(self):
+        return sum(e[2] for e in self._entries.values())
+
+
+_modes_cache = _ModesCache()
+
+
 def residue_mass(res_name):
     try:
         import biotite.structure.info as info  # optional dependency
@@ -60,11 +123,20 @@ class ElasticNetworkModel:
         self._inv_sqrt_mass = None if self._masses is None else 1 / np.sqrt(self._masses)
         self._matrix = None
         self._covariance = None
-        self._modes = None   # device-resident eigenpairs, only while no host matrix exists (see _modes_device)
 
     @property
     def masses(self):
         return self._masses
+
+    def release_device_cache(self):
+        """Free the device-resident eigenpairs kept for this model (the next consumer call solves again)."""
+        _modes_cache.drop(self)
+
+    def __del__(self):
+        try:
+            _modes_cache.drop(self)
+        except Exception:
+            pass
 
     def _size(self):
         return len(self._coord) * self._dim
@@ -73,7 +145,7 @@ class ElasticNetworkModel:
     def _get_matrix(self):
         # the matrix object handed out may be edited in place (anm.py:53 "not a copy"), so cached eigenpairs
         # cannot be trusted from here on
-        self._modes = None
+        _modes_cache.drop(self)
         if self._matrix is None:
             if self._covariance is None:
                 self._matrix, _ = _assemble(self._coord, self._ff, self._dim, self._inv_sqrt_mass)
@@ -89,10 +161,10 @@ class ElasticNetworkModel:
             raise error(f"Expected shape {(n, n)}, got {value.shape}")
         self._matrix = value
         self._covariance = None
-        self._modes = None
+        _modes_cache.drop(self)
 
     def _get_covariance(self):
-        self._modes = None
+        _modes_cache.drop(self)
         if self._covariance is None:
             from . import nma
 
@@ -105,20 +177,22 @@ class ElasticNetworkModel:
             raise IndexError(f"Expected shape {(n, n)}, got {value.shape}")
         self._covariance = value
         self._matrix = None
-        self._modes = None
+        _modes_cache.drop(self)
 
     # ---- eigensolve ---------------------------------------------------------------------------
     def _modes_device(self):
         """
         All eigenpairs as a device-resident :class:`_hip.Modes`.  While neither the matrix nor the covariance
         has been handed out to the caller (so nobody can have edited it) and the force field is evaluated on
-        the device, the object is kept: ``eigen`` / ``frequencies`` / ``mean_square_fluctuation`` / ``dcc`` then
-        share ONE solve, where the reference solves again for each (nma.py:61 via :99, :161, :330).  Otherwise
-        the current host matrix is solved, every time, as the reference does.
+        the device, the object is kept in a byte-bounded LRU (:class:`_ModesCache`): ``eigen`` / ``frequencies`` /
+        ``mean_square_fluctuation`` / ``dcc`` then share ONE solve, where the reference solves again for each
+        (nma.py:61 via :99, :161, :330).  ``release_device_cache()`` drops it explicitly.  Otherwise the current
+        host matrix is solved, every time, as the reference does.
         """
         if self._matrix is None and self._covariance is None:
-            if self._modes is not None:
-                return self._modes
+            cached = _modes_cache.get(self)
+            if cached is not None:
+                return cached
             ff_desc, patch, fused = device_plan(self._ff)
             if fused:
                 coord = _validated_coord(self._coord, self._ff)
@@ -127,8 +201,9 @@ class ElasticNetworkModel:
                 ism = None
                 if self._inv_sqrt_mass is not None:
                     ism = np.ascontiguousarray(self._inv_sqrt_mass, dtype=np.float64)
-                self._modes = _hip.Modes.from_coord(_hip.context(), coord, self._dim, ff_desc, patch_desc, ism)
-                return self._modes
+                modes = _hip.Modes.from_coord(_hip.context(), coord, self._dim, ff_desc, patch_desc, ism)
+                _modes_cache.put(self, modes)   # byte-bounded LRU shared by all models; may evict older entries
+                return modes
         matrix = self._get_matrix()
         return _hip.Modes.from_matrix(_hip.context(), matrix, self._dim)
 

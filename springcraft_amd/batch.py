@@ -66,6 +66,10 @@ class DeviceBatchSolver:
         out = {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2]}
         if t[5] > 0:   # two-stage tridiagonalisation
             out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_fused_ms=t[5])
+            for name in ("panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update"):
+                ms = C.c_double(0.0)
+                if self._L.sc_last_eigh_phase_ms(self.ctx.handle, name.encode(), C.byref(ms)) == 0:
+                    out[name + "_ms"] = ms.value
         else:
             out.update(two_stage=False, symv_ms=t[3], syr2k_ms=t[4])
         return out

@@ -348,6 +348,14 @@ int sc_last_eigh_timings(sc_ctx* ctx, double* out6) {
   return SC_OK;
 }
 
+int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms) {
+  if (!ctx || !name || !ms) return SC_ERR_INVALID_ARG;
+  for (const auto& p : ctx->phases)
+    if (p.first == name) { *ms = p.second; return SC_OK; }
+  *ms = 0.0;
+  return sc_set_error(ctx, SC_ERR_INVALID_ARG, "no phase named '%s' in the last profiled eigensolve", name);
+}
+
 int sc_contacts(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
                 const sc_patch_desc* patch, int64_t* counts, int64_t* n_pairs) {
   SC_TRY(check_coord_args(ctx, coord, n));

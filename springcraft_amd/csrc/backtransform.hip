@@ -183,15 +183,21 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
                      sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
   SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile, 1, false, false, kGemmAmBk));
 
+  PhaseTimer t_w(ctx, "bt1_w", st), t_u(ctx, "bt1_update", st);
   for (int p = npanels - 1; p >= 0; --p) {
     const int mrow = n - p * nbt - off;
+    t_w.start();
     SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s, false, false,
                            kGemmAkBk));
     hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
+    t_w.stop();
+    t_u.start();
     SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile, 1, false, false,
                            kGemmAmBk));
+    t_u.stop();
   }
   SC_HIP(ctx, hipGetLastError());
+  t_w.finish(); t_u.finish();
   SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload
   return SC_OK;
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/springcraft_hip.h"
@@ -32,6 +33,44 @@ struct sc_ctx {
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
   bool profiling = false;
   double last_timings[6] = {0, 0, 0, 0, 0, 0};
+  // named kernel-group durations of the most recent profiled eigensolve (sc_last_eigh_phase_ms)
+  std::vector<std::pair<std::string, double>> phases;
+};
+
+// Sum of the device time between start() / stop() pairs on one stream (HIP events; profiling runs only).  The events are
+// resolved in finish(), which synchronises on the last one; destroyed with the object on every return path.
+class PhaseTimer {
+ public:
+  PhaseTimer(sc_ctx* ctx, const char* name, hipStream_t st) : ctx_(ctx), name_(name), st_(st), on_(ctx->profiling) {}
+  ~PhaseTimer() { for (hipEvent_t e : ev_) (void)hipEventDestroy(e); }
+  void start() { mark(); }
+  void stop() { mark(); }
+  // stores the sum under `name` in ctx->phases; call after everything timed has been enqueued
+  void finish() {
+    if (!on_ || ev_.size() < 2) return;
+    double total = 0.0;
+    if (hipEventSynchronize(ev_.back()) != hipSuccess) return;
+    for (size_t i = 0; i + 1 < ev_.size(); i += 2) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev_[i], ev_[i + 1]) == hipSuccess) total += ms;
+    }
+    for (auto& p : ctx_->phases)
+      if (p.first == name_) { p.second = total; return; }
+    ctx_->phases.emplace_back(name_, total);
+  }
+ private:
+  void mark() {
+    if (!on_) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { on_ = false; return; }
+    (void)hipEventRecord(e, st_);
+    ev_.push_back(e);
+  }
+  sc_ctx* ctx_;
+  std::string name_;
+  hipStream_t st_;
+  bool on_;
+  std::vector<hipEvent_t> ev_;
 };
 
 int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);

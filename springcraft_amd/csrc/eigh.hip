@@ -5,6 +5,7 @@
 // allocation per context (sc_ctx::ws), sized by eigh_workspace_bytes().
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "eigh_internal.h"
@@ -213,6 +214,8 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   }
   float ms_symv = 0.f, ms_syr2k = 0.f;
   double* sb_ws = (double*)(base + P.off_sb);
+  std::unique_ptr<PhaseTimer> t_tf;   // T factors of the stage-2 diamonds (second stream)
+  if (prof) ctx->phases.clear();
   SC_TRY(prepare_matrix_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL));
   if (P.two) {
     // [3] / [4] then carry the stage-1 / stage-2 times
@@ -230,13 +233,19 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   } else {
     static const bool no_aux = getenv("SPRINGCRAFT_NO_AUX") != nullptr;
     if (P.two && no_aux) {
+      t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", st));
+      t_tf->start();
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, st));
+      t_tf->stop();
     } else if (P.two) {
       // the diamonds' T factors do not depend on the tridiagonal eigenproblem: second stream, alongside the D&C
       SC_TRY(sc_aux_stream(ctx));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
       SC_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+      t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", ctx->aux_stream));
+      t_tf->start();
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, ctx->aux_stream));
+      t_tf->stop();
       SC_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
     }
     double* dc_ws = (double*)(base + P.off_dc);
@@ -270,6 +279,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     // back-transforms the stage-2 reflectors (k_bt2_fused); [5] = 0 marks the one-stage path
     ctx->last_timings[5] = 0.0;
     if (P.two) ctx->last_timings[5] = vectors ? ms_bt2 : 1e-9;
+    if (t_tf) t_tf->finish();
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
   SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads

@@ -767,6 +767,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   double* d_big = nullptr;
   if (n > kLdsCapSetup) SC_HIP(ctx, hipMalloc((void**)&d_big, (size_t)batch * 3 * n * sizeof(double)));
 
+  PhaseTimer t_gemm(ctx, "dc_gemm", st);
   for (int l = 0; l < nlev; ++l) {
     const auto& nodes = tree.levels[l];
     const int G = (int)nodes.size();
@@ -808,7 +809,9 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                        dim3(256), 0, st, d_dc_ws, DL, dn, w_new);
     hipLaunchKernelGGL(k_dc_copy_deflated, dim3((unsigned)maxN, (unsigned)G, (unsigned)batch), dim3(256), 0, st,
                        d_dc_ws, DL, dn, q_old, q_new, stride_q);
+    t_gemm.start();
     SC_TRY(launch_gemm_f64(ctx, descs, 2 * G * batch, (maxN + 1) / 2, maxN, kGemmTile, 1, /*gather=*/true));
+    t_gemm.stop();
   }
   const long long w_final = (nlev % 2 == 0) ? DL.w0 : DL.w1;
   hipLaunchKernelGGL(k_dc_unscale, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st,
@@ -818,6 +821,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   int h_fail = 0;
   SC_HIP(ctx, hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
   SC_HIP(ctx, hipStreamSynchronize(st));  // also keeps flat / h_descs alive until the copies are done
+  t_gemm.finish();
   if (d_big) SC_HIP(ctx, hipFree(d_big));
   SC_HIP(ctx, hipFree(d_nodes));
   if (h_fail) return sc_set_error(ctx, SC_ERR_NOCONV, "tridiagonal QL iteration did not converge");

@@ -937,6 +937,9 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 //     (global_load_lds_dwordx4, no staging registers) while the current product runs: region A (V^T fragments) is refilled
 //     during product 2, region B during product 1; two barriers per diamond.  A diamond is read from L2 / HBM once per
 //     128 columns instead of once per 32.
+#ifndef BT2_DBG
+#define BT2_DBG 0
+#endif
 constexpr int kF1 = 80, kF2 = 104;                 // fragments per diamond: product 1 / product 2
 constexpr int kFragDoubles = (kF1 + kF2) * 64;     // 11776 doubles = 92 KB
 // product 1, issue order (rt, r, st): Z tile rt register r is the B operand; sweep tiles st = max(0, rt - 4) .. min(3, rt)
@@ -1105,7 +1108,8 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restrict__ sb_all, SbLayout SL,
                                                           const int* __restrict__ dia_off, double* __restrict__ z_all,
                                                           long long stride_z, int ncols, int batch, int xcd_map) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [kF1 * 64] region A | [kF2 * 64] region B
+  constexpr int dbg = BT2_DBG;   // ablation builds only (tools/ablate_bt2.sh): 1 no fragment DMA, 2 no Z traffic, 4 no MFMAs
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // regions A0 | A1 (kF1 * 64 each) | B (kF2 * 64)
   const int n = SL.n;
   constexpr int kCols = 16 * NW;
   int mat, chunk;
@@ -1122,29 +1126,66 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   const double* sb = sb_all + (size_t)mat * SL.slab;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  const int col = chunk * kCols + 16 * w + fr;
-  const bool col_ok = col < ncols;
-  // this lane's column of Z, rows offset by fk: element (tile row 4 r + fk) of a tile starting at row0 is zc[row0 + 4 r]
-  zptr zc = (zptr)(z_all + (size_t)mat * stride_z + (size_t)(col_ok ? col : ncols - 1) * n);
-  const double* ldsA = lds + lane;
-  const double* ldsB = lds + kF1 * 64 + lane;
+  const int col = chunk * kCols + 16 * w + fr;          // this lane's column in the accumulator layout
+  const double col_mask = col < ncols ? 1.0 : 0.0;
+  const double* ldsB = lds + 2 * kF1 * 64 + lane;
 
-  // (the mask is applied by a multiplication: a select lets hipcc sink the load under a branch and wait for each one;
-  //  Z holds finite numbers and the clamped address is inside the matrix)
-  const double col_mask = col_ok ? 1.0 : 0.0;
-  auto load_tile = [&](d4& t, int row0) {
+  // ---- Z <-> accumulator tiles.  In the accumulator layout a lane owns (row 4 r + fk, column fr): a global access in
+  // that shape is 16 columns x 32 bytes per instruction, which the memory path serves at ~3 TB/s (measured: the Z
+  // traffic alone then takes longer than all MFMAs).  So global memory is touched in the row-contiguous shape - lane l
+  // moves 16 bytes: rows 2 (l & 7), + 1 of column (l >> 3) [and of column (l >> 3) + 8 in a second instruction], i.e.
+  // 8 full 128-byte column segments per instruction - and each 16 x 16 tile is transposed through a wave-private LDS
+  // tile [column][18] on its way to / from the accumulator layout (LDS executes a wave's accesses in order: no waits).
+  constexpr int kStg = 16 * 18;
+  double* stg = lds + (2 * kF1 + kF2) * 64 + w * kStg;
+  const int gc = lane >> 3, gr = (lane & 7) * 2;
+  const int col_a = chunk * kCols + 16 * w + gc, col_b = col_a + 8;
+  double* z_mat = z_all + (size_t)mat * stride_z;
+  zptr za = (zptr)(z_mat + (size_t)(col_a < ncols ? col_a : ncols - 1) * n + gr);
+  zptr zb = (zptr)(z_mat + (size_t)(col_b < ncols ? col_b : ncols - 1) * n + gr);
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  typedef const d2u __attribute__((address_space(1)))* z2ptr_c;
+  typedef d2u __attribute__((address_space(1)))* z2ptr;
+  struct Raw { d2u a, b; };   // one tile as it comes from / goes to memory
+  // raw load, branch-free and without a use of the values (they are consumed much later; a select or a branch here makes
+  // hipcc wait for every load on the spot).  A tile that sticks out of the matrix is loaded from rows n - 16 .. n - 1
+  // instead and shifted back when it is scattered.
+  auto load_raw = [&](Raw& t, int row0) {
+    const int rs = row0 < n - 16 ? row0 : n - 16;
+    t.a = *(z2ptr_c)(za + rs);
+    t.b = *(z2ptr_c)(zb + rs);
+  };
+  // raw tile -> accumulator layout, rows beyond the matrix and columns beyond ncols masked to zero
+  auto scatter_tile = [&](d4& t, const Raw& raw, int row0) {
+    *(d2u*)(stg + gc * 18 + gr) = raw.a;
+    *(d2u*)(stg + (gc + 8) * 18 + gr) = raw.b;
+    asm volatile("" ::: "memory");   // compiler ordering only: the tile is read back through another type
+    const int shift = row0 < n - 16 ? 0 : row0 - (n - 16);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * r + fk;
-      const double v = zc[row < n ? row : n - 1];
-      t[r] = v * (row < n ? col_mask : 0.0);
+      const int i = 4 * r + fk + shift;
+      t[r] = stg[fr * 18 + (i < 16 ? i : 15)] * (row0 + 4 * r + fk < n ? col_mask : 0.0);
     }
+    asm volatile("" ::: "memory");
   };
   auto store_tile = [&](const d4& t, int row0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * r + fk;
-      if (row < n && col_ok) zc[row] = t[r];
+    for (int r = 0; r < 4; ++r) stg[fr * 18 + 4 * r + fk] = t[r];
+    asm volatile("" ::: "memory");
+    const d2u va = *(const d2u*)(stg + gc * 18 + gr), vb = *(const d2u*)(stg + (gc + 8) * 18 + gr);
+    asm volatile("" ::: "memory");
+    if (row0 + 16 <= n) {
+      if (col_a < ncols) *(z2ptr)(za + row0) = va;
+      if (col_b < ncols) *(z2ptr)(zb + row0) = vb;
+    } else {
+      if (col_a < ncols) {
+        if (row0 + gr < n) za[row0] = va[0];
+        if (row0 + gr + 1 < n) za[row0 + 1] = va[1];
+      }
+      if (col_b < ncols) {
+        if (row0 + gr < n) zb[row0] = vb[0];
+        if (row0 + gr + 1 < n) zb[row0 + 1] = vb[1];
+      }
     }
   };
   // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a fragment block; the waves share the instructions.
@@ -1177,14 +1218,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
     int win = S * kG + 1;
     const double* fcur = sb + SL.frag + (size_t)d0 * kFragDoubles;
+    {
+      Raw raw[8];
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) load_tile(zt[rt], win + 16 * rt);
-    barrier();                       // the previous group's last product 2 has left region A's neighbours alone; A is free
-    dma(fcur, 0, kF1 / 2);
+      for (int rt = 0; rt < 8; ++rt) load_raw(raw[rt], win + 16 * rt);
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) scatter_tile(zt[rt], raw[rt], win + 16 * rt);
+    }
+    barrier();                       // every wave has left the previous group's products: all regions are free
+    dma(fcur, 0, kF1 / 2);           // region A0 <- first diamond
     wait_vm0();
     __builtin_amdgcn_sched_barrier(0);
     for (int k = 0; k < nk; ++k, fcur += kFragDoubles) {
-      barrier();                     // X1: region A (diamond k) complete in LDS; every wave is done with region B
+      const bool more = k + 1 < nk;
+      const double* ldsA = lds + (k & 1) * (kF1 * 64) + lane;
+      barrier();                     // X1: region A[k & 1] complete in LDS; every wave is done with B and with A[(k + 1) & 1]
+      // both DMAs of this diamond go out here: its -(V T) fragments (needed after product 1) and the V^T fragments of
+      // the NEXT diamond into the other A region (needed a whole diamond later)
+      if (!(dbg & 1)) {
+        dma(fcur + kF1 * 64, 2 * kF1 * 64, kF2 / 2);
+        if (more) dma(fcur + kFragDoubles, ((k + 1) & 1) * (kF1 * 64), kF1 / 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- W1 = V^T Z
       // (fragments in groups of 8: the next group is read from LDS while the MFMAs of the current one issue)
       d4 w1[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
@@ -1193,14 +1248,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) fa[0][j] = ldsA[j * 64];
 #pragma unroll
-        for (int g = 0; g < kF1 / 8; ++g) {
+        for (int g = 0; g < ((dbg & 4) ? 1 : kF1 / 8); ++g) {
           if (g + 1 < kF1 / 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsA[((g + 1) * 8 + j) * 64];
           }
-          // region B's DMA goes out behind the first fragment groups, when the stores of the last slide have drained
-          // (hipcc makes the reuse of their registers wait for them) and still 56 MFMAs before the data is needed
-          if (g == 3) dma(fcur + kF1 * 64, kF1 * 64, kF2 / 2);
           __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g + 1 in front of the MFMAs of group g
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -1210,32 +1262,31 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      wait_vm0();
-      barrier();                     // X2: region B complete; every wave is done with region A
-      const bool more = k + 1 < nk;
-      d4 zn[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+      // X2: region B complete (this wave's part: all but its kF1 / 2 / NW youngest DMA instructions, which are the next
+      // diamond's A fragments and stay in flight)
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kF1 / 2 / NW) : "memory");
+      else wait_vm0();
+      barrier();
+      Raw zn[4];
       // ---- Z -= (V T) W1
       {
         double fb[2][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) fb[0][j] = ldsB[j * 64];
 #pragma unroll
-        for (int g = 0; g < kF2 / 8; ++g) {
+        for (int g = 0; g < ((dbg & 4) ? 3 : kF2 / 8); ++g) {
           if (g + 1 < kF2 / 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) fb[(g + 1) & 1][j] = ldsB[((g + 1) * 8 + j) * 64];
           }
-          if (g == 2 && more) {
-            dma(fcur + kFragDoubles, 0, kF1 / 2);   // region A of the next diamond
-            // the 64 rows that enter the window next are not touched by this diamond: fetch them behind the MFMAs
-            // (raw: with an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of a loaded value; masked at the slide)
+          if (g == 2 && !(dbg & 2)) {
+            // the 64 rows that enter the window next are not touched by this diamond: fetch them behind the MFMAs.
+            // Raw values, masked at the slide; issued and consumed in EVERY iteration (after the last diamond of a group
+            // they are not needed, the clamped addresses are still valid): hipcc's wait-count bookkeeping is not path
+            // sensitive, and loads that are only issued / consumed under `more` stay "maybe pending" around the loop,
+            // which costs a vmcnt(0) wherever their registers are reused (measured: 25 % of the wave cycles).
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = win + 128 + 16 * t + 4 * r + fk;
-                zn[t][r] = zc[row < n ? row : n - 1];
-              }
+            for (int t = 0; t < 4; ++t) load_raw(zn[t], win + 128 + 16 * t);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1246,22 +1297,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // ---- slide by 64 rows
-      if (more) {
-        wait_vm0();                  // next diamond's region A part of this wave + the new rows (issued a product ago)
+      // ---- slide by 64 rows (the shift is done after the last diamond of a group as well: its result is not used, but
+      // the new rows' loads must have their first use on every path, see above)
+      wait_vm0();                    // the new rows (issued a product ago) and this wave's part of the next A region
+      if (dbg & 2) {
+      } else if (more) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) store_tile(zt[t], win + 16 * t);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          zt[t] = zt[t + 4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zt[t + 4][r] = zn[t][r] * (win + 128 + 16 * t + 4 * r + fk < n ? col_mask : 0.0);
-        }
-        win += 64;
       } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t) store_tile(zt[t], win + 16 * t);
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        zt[t] = zt[t + 4];
+        scatter_tile(zt[t + 4], zn[t], win + 128 + 16 * t);
+      }
+      win += 64;
       // nothing of the slide (the masking of the new rows is the first use of their loads) may sink into the next
       // diamond: behind its LDS-DMA issue the compiler would wait vmcnt(0) for it
       __builtin_amdgcn_sched_barrier(0);
@@ -1419,11 +1471,13 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const size_t lds_blk_a = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kQrRows + 8 * kB);
   const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
   static const bool blocked_qr = getenv("SPRINGCRAFT_QR_UNBLOCKED") == nullptr;
+  PhaseTimer t_qr(ctx, "panel_qr", st), t_symm(ctx, "symm", st), t_syr2k(ctx, "syr2k", st), t_bulge(ctx, "bulge", st);
   for (int p = 0; p < npanels; ++p) {
     const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
     const int nr = std::min(kB, m - 1);
     const int nchunks = (m + kQrRows - 1) / kQrRows;
     const dim3 qgrid((unsigned)nchunks, (unsigned)batch);
+    t_qr.start();
     if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
       hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, 0, nr,
@@ -1442,13 +1496,18 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
         hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, j, nr,
                            kB);
     }
+    t_qr.stop();
     const GemmDesc* g = d_descs + (size_t)p * 6 * batch;
+    t_symm.start();
     SC_TRY(launch_gemm_f64(ctx, g, batch, m, kB, kGemmTile, 1, false, true, kGemmAmBk));           // X1 = L V
     SC_TRY(launch_gemm_f64(ctx, g + batch, batch, m, kB, kGemmTile, 1, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+    t_symm.stop();
     SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
     hipLaunchKernelGGL(k_sb_small, dim3((unsigned)batch), dim3(256), lds_small, st, d_tri_ws, TL, d_sb_ws, SL, j0);
     SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+    t_syr2k.start();
     SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile, 1, false, false, kGemmAmBn));
+    t_syr2k.stop();
   }
   SC_HIP(ctx, hipGetLastError());
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
@@ -1466,8 +1525,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   if (n >= 3) {
     const int t_max = 2 * (n - 3) + chase_len(n, n - 3) - 1;
     const int gx = chase_len(n, 0) / 2 + 1;
+    t_bulge.start();
     for (int t = 0; t <= t_max; ++t)
       hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t);
+    t_bulge.stop();
   }
   hipLaunchKernelGGL(k_band_to_tri, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL,
                      d_tri_ws, TL);
@@ -1479,6 +1540,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_HIP(ctx, hipEventElapsedTime(ms_stage2, ev[1], ev[2]));
     for (auto& e : ev) (void)hipEventDestroy(e);
   }
+  t_qr.finish(); t_symm.finish(); t_syr2k.finish(); t_bulge.finish();
   SC_HIP(ctx, hipStreamSynchronize(st));   // host descriptor vectors must outlive their uploads
   return SC_OK;
 }
@@ -1487,6 +1549,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
 // T factors and V T of all diamonds, on `st` (they only depend on the bulge chase, not on Z).
 int bt2_prepare(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& SL, hipStream_t st) {
   if (n < 3 || SL.ndia == 0) return SC_OK;
+  for (auto& ph : ctx->phases)
+    if (ph.first == "dia_tfactor") ph.second = 0.0;
   for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
     const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
     if (bt2_old_path())
@@ -1521,12 +1585,13 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     }
   } else {
     // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
-    const size_t lds = sizeof(double) * kFragDoubles;
+    // regions A0 | A1 | B + one 16 x 18 transposition tile per wave
+    const size_t lds = sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18);
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * kFragDoubles));
+                                (int)(sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18)));
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * kFragDoubles));
+                                (int)(sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18)));
       return true;
     }();
     (void)attr_set;

@@ -182,14 +182,16 @@ def test_trivial_modes_rejected_and_bad_index(sc, ca):
 
 def test_eigenpairs_are_shared_until_the_matrix_is_handed_out(sc, ca):
     anm = sc.ANM(ca, sc.InvariantForceField(13))
+    from springcraft_amd._model import _modes_cache
+
     w, _ = anm.eigen()
-    modes = anm._modes
+    modes = _modes_cache.get(anm)
     assert modes is not None
     anm.mean_square_fluctuation()
     anm.dcc()
-    assert anm._modes is modes                       # one solve served all three
+    assert _modes_cache.get(anm) is modes            # one solve served all three
     h = anm.hessian                                  # "not a copy": the caller may now edit it in place
-    assert anm._modes is None
+    assert _modes_cache.get(anm) is None
     h *= 2.0
     w2, _ = anm.eigen()
     assert np.allclose(w2[6:], 2.0 * w[6:])
@@ -200,3 +202,38 @@ def test_eigenpairs_are_shared_until_the_matrix_is_handed_out(sc, ca):
     anm2.covariance = 3.0 * cov
     assert np.allclose(sc.nma.prs(anm2, norm=False), 9.0 * np_prs(np.linalg.pinv(cov, hermitian=True), False),
                        rtol=1e-6)
+
+
+def test_device_eigenpair_cache_is_bounded(sc):
+    """
+    Models that stay alive must not pin one (n, n) eigenvector matrix each in HBM (advisor finding, round 1): the
+    device-resident eigenpairs live in a byte-bounded LRU; evicted models solve again and give the same numbers.
+    """
+    from springcraft_amd import _model
+
+    cache = _model._modes_cache
+    old = cache.budget
+    cache.clear()
+    try:
+        n_atoms = 60
+        one = 8 * ((3 * n_atoms) ** 2 + 3 * n_atoms)
+        cache.budget = 3 * one + 100                     # room for three models
+        models = [sc.ANM(synthetic_coord(n_atoms, s, 15.0), sc.InvariantForceField(9.0)) for s in range(8)]
+        first = [m.eigen()[0] for m in models]
+        assert cache.nbytes() <= cache.budget and len(cache._entries) == 3
+        msf = [m.mean_square_fluctuation() for m in models]      # evicted ones solve again
+        assert cache.nbytes() <= cache.budget
+        for m, w, f in zip(models, first, msf):
+            w2, v2 = m.eigen()
+            assert np.array_equal(w, w2)
+            ref = (v2[6:] ** 2 / w2[6:, None]).sum(0).reshape(-1, 3).sum(1)
+            assert np.allclose(f, ref)
+        models[-1].release_device_cache()
+        assert cache.get(models[-1]) is None
+        cache.clear()
+        cache.budget = one - 1                            # nothing fits: every call solves, nothing is kept
+        w3, _ = models[0].eigen()
+        assert np.array_equal(w3, first[0]) and cache.nbytes() <= cache.budget
+    finally:
+        cache.budget = old
+        cache.clear()

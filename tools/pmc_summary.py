@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-for run in sorted(glob.glob(os.path.join(root, "run*"))):
+for run in sorted(glob.glob(os.path.join(root, "run*"))):  # run1, run_sq, ...
     if not os.path.isdir(run):
         continue
     files = glob.glob(os.path.join(run, "**", "*counter_collection.csv"), recursive=True)
