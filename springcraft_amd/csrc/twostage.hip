@@ -940,30 +940,44 @@ __global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__
 #ifndef BT2_DBG
 #define BT2_DBG 0
 #endif
+// Diagnostic build (-DBT2_STAMPS): per wave, the shader cycles between eight points of the diamond loop are summed and left
+// in g_bt2_stamps (read with sc_dbg_bt2_stamps, tools/bt2_stamps.py); no stamp executes in the normal build.
+#ifdef BT2_STAMPS
+__device__ unsigned long long g_bt2_stamps[64 * 8 * 9];
+#define BT2_STAMP_DECL unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
+#define BT2_STAMP(i)                                                              \
+  {                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long t_;                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+    if ((i) != 0 || st_n != 0) st_sum[i] += t_ - st_prev;                         \
+    st_prev = t_;                                                                 \
+    if ((i) == 7) ++st_n;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
+#define BT2_STAMP_WRITE                                                           \
+  if (blockIdx.x < 64 && lane == 0) {                                             \
+    for (int i = 0; i < 8; ++i) g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 9 + i] = st_sum[i]; \
+    g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 9 + 8] = st_n;                      \
+  }
+#else
+#define BT2_STAMP_DECL
+#define BT2_STAMP(i)
+#define BT2_STAMP_WRITE
+#endif
 constexpr int kF1 = 80, kF2 = 104;                 // fragments per diamond: product 1 / product 2
 constexpr int kFragDoubles = (kF1 + kF2) * 64;     // 11776 doubles = 92 KB
-// product 1, issue order (rt, r, st): Z tile rt register r is the B operand; sweep tiles st = max(0, rt - 4) .. min(3, rt)
-__host__ __device__ constexpr int p1_stlo(int rt) { return rt > 4 ? rt - 4 : 0; }
-__host__ __device__ constexpr int p1_sthi(int rt) { return rt < 3 ? rt : 3; }
-__host__ __device__ constexpr int p1_cnt(int rt) { return p1_sthi(rt) - p1_stlo(rt) + 1; }
-__host__ __device__ constexpr int p1_base(int rt) {
-  int b = 0;
-  for (int t = 0; t < rt; ++t) b += 4 * p1_cnt(t);
-  return b;
-}
-__host__ __device__ constexpr int p1_index(int rt, int r, int st) { return p1_base(rt) + r * p1_cnt(rt) + (st - p1_stlo(rt)); }
+// product 1: sweep tile st meets row tiles rt = st .. st + 4 (the reflectors' parallelogram), k-steps r = 0..3 each.  Issue
+// order: f = 4 i + st with i = 4 (rt - st) + r, i.e. the four accumulators W1[st] take turns; Z tile rt register r is
+// the B operand.
+__host__ __device__ constexpr int p1_index(int rt, int r, int st) { return 4 * (4 * (rt - st) + r) + st; }
 // product 2, issue order (st, r, rt): W1 tile st register r is the B operand; row tiles rt = 0 .. 4 + st
 __host__ __device__ constexpr int p2_base(int st) { return 4 * (5 * st + st * (st - 1) / 2); }
 __host__ __device__ constexpr int p2_index(int st, int r, int rt) { return p2_base(st) + r * (5 + st) + rt; }
-static_assert(p1_base(8) == kF1 && p2_base(4) == kF2, "fragment counts");
+static_assert(p1_index(7, 3, 3) == kF1 - 1 && p2_base(4) == kF2, "fragment counts");
 // fragment index = issue index; the inverse maps (constant-folded in the unrolled products)
 struct P1Step { int rt, r, st; };
-__host__ __device__ constexpr P1Step p1_decode(int f) {
-  int rt = 0;
-  while (rt < 7 && f >= p1_base(rt + 1)) ++rt;
-  const int rem = f - p1_base(rt), cnt = p1_cnt(rt);
-  return P1Step{rt, rem / cnt, p1_stlo(rt) + rem % cnt};
-}
+__host__ __device__ constexpr P1Step p1_decode(int f) { return P1Step{(f & 3) + (f >> 4), (f >> 2) & 3, f & 3}; }
 struct P2Step { int st, r, rt; };
 __host__ __device__ constexpr P2Step p2_decode(int f) {
   int st = 0;
@@ -1168,44 +1182,59 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     }
     asm volatile("" ::: "memory");
   };
-  auto store_tile = [&](const d4& t, int row0) {
+  // accumulator layout -> memory in two stages, so that the LDS round trip can sit in the shadow of MFMAs:
+  // stage 1 (tile_to_rows): through the staging tile into two row-contiguous register pairs; stage 2 (store_rows).
+  auto tile_to_rows = [&](const d4& t, Raw& out) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) stg[fr * 18 + 4 * r + fk] = t[r];
     asm volatile("" ::: "memory");
-    const d2u va = *(const d2u*)(stg + gc * 18 + gr), vb = *(const d2u*)(stg + (gc + 8) * 18 + gr);
+    out.a = *(const d2u*)(stg + gc * 18 + gr);
+    out.b = *(const d2u*)(stg + (gc + 8) * 18 + gr);
     asm volatile("" ::: "memory");
+  };
+  auto store_rows = [&](const Raw& v, int row0) {
     if (row0 + 16 <= n) {
-      if (col_a < ncols) *(z2ptr)(za + row0) = va;
-      if (col_b < ncols) *(z2ptr)(zb + row0) = vb;
+      if (col_a < ncols) *(z2ptr)(za + row0) = v.a;
+      if (col_b < ncols) *(z2ptr)(zb + row0) = v.b;
     } else {
       if (col_a < ncols) {
-        if (row0 + gr < n) za[row0] = va[0];
-        if (row0 + gr + 1 < n) za[row0 + 1] = va[1];
+        if (row0 + gr < n) za[row0] = v.a[0];
+        if (row0 + gr + 1 < n) za[row0 + 1] = v.a[1];
       }
       if (col_b < ncols) {
-        if (row0 + gr < n) zb[row0] = vb[0];
-        if (row0 + gr + 1 < n) zb[row0 + 1] = vb[1];
+        if (row0 + gr < n) zb[row0] = v.b[0];
+        if (row0 + gr + 1 < n) zb[row0 + 1] = v.b[1];
       }
     }
+  };
+  auto store_tile = [&](const d4& t, int row0) {
+    Raw v;
+    tile_to_rows(t, v);
+    store_rows(v, row0);
   };
   // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a fragment block; the waves share the instructions.
   // Issued from inline asm: hipcc then keeps no scoreboard entry for them (with the builtin it guards later LDS reads
   // and register reuse with vmcnt(0), i.e. waits for the DMA it has just issued); their completion is counted by hand:
   // every wait for them below is an explicit vmcnt(0).  M0 (the LDS destination base) is saved and restored.
   const unsigned lds_base = (unsigned)(size_t)(lvoid)lds;
-  auto dma = [&](const double* src, int lds_off_doubles, int n_instr) {
-    const char* g = (const char*)src + lane * 16;
-    const unsigned l = lds_base + (unsigned)lds_off_doubles * 8u;
-    for (int q = w; q < n_instr; q += NW) {
+  // this wave's j-th instruction of a block of n_instr (the waves share the instructions round robin)
+  auto dma_one = [&](const double* src, int lds_off_doubles, int n_instr, int j) {
+    const int q = w + NW * j;
+    if (q < n_instr) {
       unsigned keep;
-      const char* gq = g + q * 1024;
-      const unsigned lq = __builtin_amdgcn_readfirstlane(l + (unsigned)q * 1024u);
+      const char* gq = (const char*)src + lane * 16 + q * 1024;
+      const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)lds_off_doubles * 8u + (unsigned)q * 1024u);
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(gq), "s"(lq)
                    : "memory");
     }
   };
+  auto dma = [&](const double* src, int lds_off_doubles, int n_instr) {
+    for (int j = 0; j * NW < n_instr; ++j) dma_one(src, lds_off_doubles, n_instr, j);
+  };
+  constexpr int kBper = (kF2 / 2 + NW - 1) / NW;   // DMA instructions per wave: region B (7 or 13)
+  constexpr int kAper = (kF1 / 2 + NW - 1) / NW;   //                              region A (5 or 10)
   auto wait_vm0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto barrier = [&]() {
     asm volatile("" ::: "memory");
@@ -1214,6 +1243,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   };
 
   d4 zt[8];
+  // the 64 rows finished at the last slide: stored one diamond later, behind the MFMAs of product 2 (the 8-wave kernel
+  // only: with 4 waves the twice as many DMA instructions per wave leave no registers for it, the rows go out at the slide)
+  constexpr bool kDefer = NW == 8;
+  d4 zfin[kDefer ? 4 : 1];
+  int fin_row = 0;
+  bool have_fin = false;
+  BT2_STAMP_DECL
   for (int S = SL.ngroups - 1; S >= 0; --S) {
     const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
     int win = S * kG + 1;
@@ -1232,16 +1268,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     for (int k = 0; k < nk; ++k, fcur += kFragDoubles) {
       const bool more = k + 1 < nk;
       const double* ldsA = lds + (k & 1) * (kF1 * 64) + lane;
+      BT2_STAMP(0)
       barrier();                     // X1: region A[k & 1] complete in LDS; every wave is done with B and with A[(k + 1) & 1]
-      // both DMAs of this diamond go out here: its -(V T) fragments (needed after product 1) and the V^T fragments of
-      // the NEXT diamond into the other A region (needed a whole diamond later)
-      if (!(dbg & 1)) {
-        dma(fcur + kF1 * 64, 2 * kF1 * 64, kF2 / 2);
-        if (more) dma(fcur + kFragDoubles, ((k + 1) & 1) * (kF1 * 64), kF1 / 2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- W1 = V^T Z
-      // (fragments in groups of 8: the next group is read from LDS while the MFMAs of the current one issue)
+      BT2_STAMP(1)
+      // ---- W1 = V^T Z.  Fragments in groups of 8: the next group is read from LDS while the MFMAs of the current one
+      // issue.  Everything else a diamond needs is issued in the shadow of these MFMA runs, a little per group (measured
+      // with in-kernel stamps, profiles/r02_bt2_stamps.txt: issued in bursts in front of the products and at the slide,
+      // the LDS-DMAs and the store path cost 8k of the 34k cycles of a diamond): here the DMA of this diamond's -(V T)
+      // fragments into region B.
       d4 w1[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
       {
         double fa[2][8];
@@ -1253,6 +1287,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsA[((g + 1) * 8 + j) * 64];
           }
+          if (g < 4 && !(dbg & 1)) {
+#pragma unroll
+            for (int j = g * ((kBper + 3) / 4); j < (g + 1) * ((kBper + 3) / 4) && j < kBper; ++j)
+              dma_one(fcur + kF1 * 64, 2 * kF1 * 64, kF2 / 2, j);
+          }
           __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g + 1 in front of the MFMAs of group g
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -1262,13 +1301,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // X2: region B complete (this wave's part: all but its kF1 / 2 / NW youngest DMA instructions, which are the next
-      // diamond's A fragments and stay in flight)
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kF1 / 2 / NW) : "memory");
-      else wait_vm0();
+      BT2_STAMP(2)
+      wait_vm0();                    // X2: this wave's part of region B (nothing else of this wave is in flight)
+      BT2_STAMP(3)
       barrier();
-      Raw zn[4];
-      // ---- Z -= (V T) W1
+      BT2_STAMP(4)
+      // ---- Z -= (V T) W1.  In the shadow of its MFMAs: the loads of the 64 rows that enter the window at the slide
+      // (raw values, scattered and masked at the slide; issued and consumed in EVERY iteration - after the last diamond
+      // of a group they are not needed, the clamped addresses are still valid: hipcc's wait-count bookkeeping is not path
+      // sensitive, and loads that are only issued / consumed under `more` stay "maybe pending" around the loop, which
+      // costs a vmcnt(0) wherever their registers are reused), the DMA of the next diamond's V^T fragments into the other
+      // A region, and the store of the rows that were finished at the last slide (LDS transposition one group, the
+      // global store the next).
+      Raw zn[4], fin_rows;
       {
         double fb[2][8];
 #pragma unroll
@@ -1279,14 +1324,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) fb[(g + 1) & 1][j] = ldsB[((g + 1) * 8 + j) * 64];
           }
-          if (g == 2 && !(dbg & 2)) {
-            // the 64 rows that enter the window next are not touched by this diamond: fetch them behind the MFMAs.
-            // Raw values, masked at the slide; issued and consumed in EVERY iteration (after the last diamond of a group
-            // they are not needed, the clamped addresses are still valid): hipcc's wait-count bookkeeping is not path
-            // sensitive, and loads that are only issued / consumed under `more` stay "maybe pending" around the loop,
-            // which costs a vmcnt(0) wherever their registers are reused (measured: 25 % of the wave cycles).
+          if (g < 2 && !(dbg & 2)) {
+            load_raw(zn[2 * g], win + 128 + 32 * g);
+            load_raw(zn[2 * g + 1], win + 128 + 32 * g + 16);
+          }
+          if (g < 5 && more && !(dbg & 1)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) load_raw(zn[t], win + 128 + 16 * t);
+            for (int j = g * ((kAper + 4) / 5); j < (g + 1) * ((kAper + 4) / 5) && j < kAper; ++j)
+              dma_one(fcur + kFragDoubles, ((k + 1) & 1) * (kF1 * 64), kF1 / 2, j);
+          }
+          if (kDefer && g >= 5 && g <= 9 && have_fin && !(dbg & 2)) {
+            if (g >= 6) store_rows(fin_rows, fin_row + 16 * (g - 6));
+            if (g <= 8) tile_to_rows(zfin[kDefer ? g - 5 : 0], fin_rows);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1297,16 +1346,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // ---- slide by 64 rows (the shift is done after the last diamond of a group as well: its result is not used, but
-      // the new rows' loads must have their first use on every path, see above)
-      wait_vm0();                    // the new rows (issued a product ago) and this wave's part of the next A region
-      if (dbg & 2) {
+      // ---- slide by 64 rows: the finished rows move to zfin, the window shifts, the new rows are scattered in (the
+      // shift is done after the last diamond of a group as well: its result is not used, but the new rows' loads must
+      // have their first use on every path, see above)
+      BT2_STAMP(5)
+      wait_vm0();                    // the new rows, this wave's part of the next A region, the deferred stores
+      BT2_STAMP(6)
+      if (more && kDefer) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) zfin[kDefer ? t : 0] = zt[t];
+        fin_row = win;
+        have_fin = true;
       } else if (more) {
+        if (!(dbg & 2)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) store_tile(zt[t], win + 16 * t);
+          for (int t = 0; t < 4; ++t) store_tile(zt[t], win + 16 * t);
+        }
       } else {
+        if (!(dbg & 2)) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) store_tile(zt[t], win + 16 * t);
+          for (int t = 0; t < 8; ++t) store_tile(zt[t], win + 16 * t);
+        }
+        have_fin = false;
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -1314,11 +1375,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
         scatter_tile(zt[t + 4], zn[t], win + 128 + 16 * t);
       }
       win += 64;
-      // nothing of the slide (the masking of the new rows is the first use of their loads) may sink into the next
+      BT2_STAMP(7)
+      // nothing of the slide (the scatter of the new rows is the first use of their loads) may sink into the next
       // diamond: behind its LDS-DMA issue the compiler would wait vmcnt(0) for it
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  BT2_STAMP_WRITE
 }
 
 }  // namespace
@@ -1620,6 +1683,16 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
 }
 
 int sb_band_width() { return kB; }
+
+// ---- diagnostic build only: per-wave segment sums of k_bt2_apply (first 64 workgroups x 8 waves x (8 sums + count))
+extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
+#ifdef BT2_STAMPS
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_stamps), sizeof(unsigned long long) * 64 * 8 * 9) == hipSuccess ? 0 : 5;
+#else
+  (void)out;
+  return 1;
+#endif
+}
 
 // ---- debugging entry point (not part of the public C ABI): band after stage 1 (128 x n, AB(i,j) at [(i-j) + 128 j])
 // and the tridiagonal after stage 2 of ONE host matrix (NumPy layout, lower triangle read).

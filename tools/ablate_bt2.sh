@@ -1,9 +1,10 @@
 #!/bin/bash
-# Ablation of k_bt2_apply on the GPU box: rebuild twostage.hip with BT2_DBG = 1 (no fragment DMA), 2 (no Z loads /
-# stores), 4 (one MFMA group per product only) and time the bench step; results are wrong by construction.
+# Ablation of k_bt2_apply on the GPU box: rebuild twostage.hip with BT2_DBG = 1 (no fragment DMA), 4 (one MFMA group per
+# product only), 5 (both) and time the bench step; results are wrong by construction.  (2 = no Z traffic lets the
+# compiler delete the products as dead code: not meaningful.)
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
-for d in 0 1 2 3 4 5 6 7; do
+for d in ${1:-0 1 4 5}; do
   touch springcraft_amd/csrc/twostage.hip
   SC_EXTRA_HIPCC_FLAGS="-DBT2_DBG=$d" python springcraft_amd/csrc/build.py > /dev/null 2>&1
   timeout -k 10 120 python bench.py --no-cpu-baseline --steps 1 --warmup 1 > gpurun_out/abl_$d.json 2>/dev/null

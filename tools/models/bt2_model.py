@@ -29,8 +29,9 @@ def mfma(a_frag, b_frag, c):
 
 
 def p1_steps():
-    """product 1 (W1 = V^T Z): (rt, r, st) in issue order; B operand = Z tile rt register r."""
-    return [(rt, r, st) for rt in range(8) for r in range(4) for st in range(max(0, rt - 4), min(3, rt) + 1)]
+    """product 1 (W1 = V^T Z): (rt, r, st) in issue order f = 4 i + st, i = 4 (rt - st) + r: the four accumulators take
+    turns; B operand = Z tile rt register r."""
+    return [(st + i // 4, i % 4, st) for i in range(20) for st in range(4)]
 
 
 def p2_steps():

@@ -165,6 +165,8 @@ int main(int argc, char** argv) {
   const int iters = 4000;
   for (int wps : {1, 2, 4}) {
     const int blocks = cus * wps;
+    run("regs x1", wps, iters * 1.0, [&]() { hipLaunchKernelGGL(k_regs<1>, dim3(blocks), dim3(256), 0, 0, d_rand, d_out, d_st, iters); }, d_st, blocks * 4, soak);
+    run("regs x2", wps, iters * 2.0, [&]() { hipLaunchKernelGGL(k_regs<2>, dim3(blocks), dim3(256), 0, 0, d_rand, d_out, d_st, iters); }, d_st, blocks * 4, soak);
     run("regs x4", wps, iters * 4.0, [&]() { hipLaunchKernelGGL(k_regs<4>, dim3(blocks), dim3(256), 0, 0, d_rand, d_out, d_st, iters); }, d_st, blocks * 4, soak);
     run("regs x8", wps, iters * 8.0, [&]() { hipLaunchKernelGGL(k_regs<8>, dim3(blocks), dim3(256), 0, 0, d_rand, d_out, d_st, iters); }, d_st, blocks * 4, soak);
     run("regs x16", wps, iters * 16.0, [&]() { hipLaunchKernelGGL(k_regs<16>, dim3(blocks), dim3(256), 0, 0, d_rand, d_out, d_st, iters); }, d_st, blocks * 4, soak);
