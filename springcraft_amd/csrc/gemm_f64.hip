@@ -269,8 +269,12 @@ struct StageImage {
 typedef const double __attribute__((address_space(1)))* gptr_c;   // loads through these are global_load, not flat_load
 typedef double __attribute__((address_space(1)))* gptr;             // (a flat access also counts on lgkmcnt: the barrier's wait would wait for it)
 
-template <int BM, int BN, bool AM, bool BNC, bool TRI>
+// GATHER (layout "A m-contiguous, B k-contiguous" only; the merges of the tridiagonal divide & conquer): A's k axis and B's
+// k axis go through the records' index lists, C's columns through c_jidx.  The indices of a K step are loaded one K
+// step before the operands that need them, so the dependent load pair is never waited for.
+template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k) {
+  static_assert(!GATHER || (AM && !BNC && !TRI), "gather lists: A m-contiguous, B k-contiguous, no triangular mask");
   constexpr int BK = 16;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
@@ -336,10 +340,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   }
 
   double ra[A_PER], rb[B_PER];
+  // gather lists: this thread's k indices of the K step whose operands are loaded next
+  const int* __restrict__ a_kidx = GATHER ? D.a_kidx : nullptr;
+  const int* __restrict__ b_kidx = GATHER ? D.b_kidx : nullptr;
+  int ia[GATHER ? A_PER : 1], ib = 0;
+  long long b_col[GATHER ? B_PER : 1];   // byte offsets of this thread's B columns
+  if (GATHER) {
+#pragma unroll
+    for (int p = 0; p < B_PER; ++p) b_col[p] = (long long)min(n0 + bx + p * B_XSTEP, N - 1) * sb * 8;
+  }
+  auto i_load = [&](int kt) {
+    if (GATHER) {
+#pragma unroll
+      for (int p = 0; p < A_PER; ++p) {
+        const int k = min(kt + ak + p * A_KSTEP, K - 1);
+        ia[p] = a_kidx ? a_kidx[k] : k;
+      }
+      const int kb = min(kt + bk, K - 1);
+      ib = b_kidx ? b_kidx[kb] : kb;
+    }
+  };
   // Raw loads, always in bounds; the masks are applied when the registers go to LDS, one MFMA run later, so that
   // nothing in between waits for the loads.  Full K steps (no clamp on k): thread base + uniform offsets only.
   auto g_load = [&](int kt) {
-    if (kt + BK <= K) {
+    if (GATHER) {
+      const char* arow = Ab + (long long)min(m0 + ax, M - 1) * 8;
+#pragma unroll
+      for (int p = 0; p < A_PER; ++p) ra[p] = *(gptr_c)(arow + (long long)ia[p] * sa * 8);
+#pragma unroll
+      for (int p = 0; p < B_PER; ++p) rb[p] = *(gptr_c)(Bb + b_col[p] + (long long)ib * 8);
+      i_load(kt + BK);
+    } else if (kt + BK <= K) {
       if (AM) {
         const char* t0 = Ab + a_thr + (long long)kt * sa * 8;
 #pragma unroll
@@ -420,7 +451,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
-        gptr_c ccol = C + (long long)min(col, N - 1) * ldc;
+        const int colc = min(col, N - 1);
+        gptr_c ccol = C + (long long)((GATHER && D.c_jidx) ? D.c_jidx[colc] : colc) * ldc;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           const int row = m0 + wm * WM + mi * 16 + fr;
@@ -428,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
         }
       }
   }
+  if (GATHER && K > 0) i_load(k_begin);
   if (k_begin < k_end) g_load(k_begin);
   else {
 #pragma unroll
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
     for (int r = 0; r < 4; ++r) {
       const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
       if (col >= N) continue;
-      gptr ccol = C + (long long)col * ldc;
+      gptr ccol = C + (long long)((GATHER && D.c_jidx) ? D.c_jidx[col] : col) * ldc;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int row = m0 + wm * WM + mi * 16 + fr;
@@ -504,16 +537,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
 }
 
 // One instantiation per (block tile, layout, triangular A); its dynamic LDS size is raised above the 64 KB default once.
-template <int BM, int BN, bool AM, bool BNC, bool TRI>
+template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
 void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k) {
   constexpr size_t lds = sizeof(double) * 2 * (size_t)(StageImage<BM, AM>::kSize + StageImage<BN, BNC>::kSize);
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI, GATHER>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI>), grid, dim3(256), lds, st, d_desc, split_k);
+  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k);
 }
 
 template <int BM, int BN, bool TRI>
@@ -560,6 +593,20 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
   hipStream_t st = ctx->stream;
+  static const bool gather_old = getenv("SPRINGCRAFT_GEMM_GATHER_OLD") != nullptr;
+  if (gather && !tri && layout == kGemmAmBk && gemm2_enabled() && !gather_old) {
+    // merges of the divide & conquer: 128 x 64 tiles while they fill the chip, else 64 x 64
+    const long long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const long long gz = (long long)count * split_k;
+    if (gz > 65535) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "GEMM launch with %lld records x slices (max 65535)", gz);
+    const bool big = max_m > 64 && (long long)((max_m + 127) / 128) * ((max_n + 63) / 64) * gz >= 2 * cus;
+    const int bm = big ? 128 : 64;
+    dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + 63) / 64), (unsigned)gz);
+    if (big) launch_gemm2_inst<128, 64, true, false, false, true>(st, grid, d_desc, split_k);
+    else launch_gemm2_inst<64, 64, true, false, false, true>(st, grid, d_desc, split_k);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+  }
   if (!gather && layout >= 0 && layout <= 2 && !(tri && layout == kGemmAmBn) && gemm2_enabled()) {
     int bm, bn;
     gemm2_tile(ctx, count, max_m, max_n, split_k, layout, &bm, &bn);

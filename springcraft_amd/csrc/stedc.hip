@@ -810,7 +810,8 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     hipLaunchKernelGGL(k_dc_copy_deflated, dim3((unsigned)maxN, (unsigned)G, (unsigned)batch), dim3(256), 0, st,
                        d_dc_ws, DL, dn, q_old, q_new, stride_q);
     t_gemm.start();
-    SC_TRY(launch_gemm_f64(ctx, descs, 2 * G * batch, (maxN + 1) / 2, maxN, kGemmTile, 1, /*gather=*/true));
+    SC_TRY(launch_gemm_f64(ctx, descs, 2 * G * batch, (maxN + 1) / 2, maxN, kGemmTile, 1, /*gather=*/true, false,
+                           kGemmAmBk));
     t_gemm.stop();
   }
   const long long w_final = (nlev % 2 == 0) ? DL.w0 : DL.w1;
