@@ -1,13 +1,17 @@
 // Back-transformation  Z <- Q_H Z  (stage K7): applies the Householder reflectors of the
-// tridiagonalisation, NBT = 128 at a time, as compact-WY block reflectors  I - V T V^T  so that all O(n^3)
+// tridiagonalisation, NBT = 256 at a time, as compact-WY block reflectors  I - V T V^T  so that all O(n^3)
 // work is f64-MFMA GEMM (the role of LAPACK dormtr inside np.linalg.eigh, reference call site nma.py:61).
 //
 // Everything that does not depend on Z is done once, for ALL blocks, in four launches:
 //   k_bt_clean      zero, in place, the entries of A above each reflector's unit entry inside its block (A is
 //                   scratch by now), so V_p is a plain sub-matrix view of A
 //   GEMM (grouped, split-K)   G_p = V_p^T V_p
-//   k_bt_tfactor    T_p from tau and G_p (dlarft recurrence, forward / columnwise), one workgroup per block
+//   k_bt_tfactor    the two 128 x 128 diagonal blocks T1, T2 of T_p from tau and G_p (dlarft recurrence, forward /
+//                   columnwise, one workgroup per diagonal block: 128 x 128 is what fits in LDS)
+//   2 GEMMs         the off-diagonal block  T12 = -T1 (V1^T V2) T2  (larft's blocked form)
 //   GEMM (grouped)  VT_p = V_p T_p
+// Blocks of 256 instead of 128 reflectors halve the passes over Z (each block reads Z once for W1 and reads and
+// writes it once for the update: at K = 128 that traffic, not the MFMAs, set the pace: 866 + 433 GB per step).
 // and then, last block first, three launches per block:
 //   GEMM (split-K)  W1 = V_p^T Z[rows]        (NBT x n, K = rows: split so the grid fills the chip)
 //   k_bt_sum        W  = sum of the K slices
@@ -19,7 +23,8 @@
 
 namespace {
 
-constexpr int kNbt = 128;
+constexpr int kNbt = 256;    // reflectors per block
+constexpr int kNbtT = 128;   // diagonal blocks of T computed by the recurrence
 constexpr int kGramSplits = 4;
 
 __global__ __launch_bounds__(256) void k_bt_clean(double* __restrict__ a_all, long long stride_a, int n,
@@ -37,21 +42,38 @@ __global__ __launch_bounds__(256) void k_bt_clean(double* __restrict__ a_all, lo
     for (int r = cs + off + threadIdx.x; r < n; r += blockDim.x) A[(size_t)c * n + r] = 0.0;
 }
 
-// T (upper triangular, nbt x nbt, column-major) from the Gram slices and tau; grid (block, matrix).
+// Diagonal 128 x 128 blocks of T (upper triangular, nbt x nbt, column-major) from the Gram slices and tau; grid (2 x block,
+// matrix).  The first workgroup of a block also sums the Gram slices of the off-diagonal block G12 = V1^T V2 into g12 and
+// zeroes the lower-left block of T.
 __global__ __launch_bounds__(256) void k_bt_tfactor(const double* __restrict__ tri_all, TriLayout TL,
                                                     double* __restrict__ bt_all, BtLayout BL, int nref) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int nt = kNbtT;
   const int nbt = BL.nbt;
-  double* T = sm;               // nbt x nbt
-  double* gcol = sm + nbt * nbt;
-  const int p = blockIdx.x;
+  double* T = sm;               // nt x nt
+  double* gcol = sm + nt * nt;
+  const int p = blockIdx.x >> 1, h = blockIdx.x & 1;
   const double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
   double* bt = bt_all + (size_t)blockIdx.y * BL.slab;
-  const double* gram = bt + BL.gram + (size_t)p * BL.splits_g * nbt * nbt;
-  const int cs = p * nbt;
-  const int kk = std::min(nbt, nref - cs);
+  const double* gram_p = bt + BL.gram + (size_t)p * BL.splits_g * nbt * nbt;
+  const double* gram = gram_p + (size_t)(h * nt) * nbt + h * nt;   // diagonal block h
+  double* tout = bt + BL.t + (size_t)p * nbt * nbt;
+  const int cs = p * nbt + h * nt;
+  const int kk = std::max(0, std::min(nt, nref - cs));
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) T[idx] = 0.0;
+  for (int idx = tid; idx < nt * nt; idx += blockDim.x) T[idx] = 0.0;
+  if (h == 0) {
+    double* g12 = bt + BL.g12 + (size_t)p * nt * nt;
+    const int pc = std::min(nbt, BL.n - p * nbt);   // columns of this block that exist: the Gram product wrote pc x pc
+    for (int idx = tid; idx < nt * nt; idx += blockDim.x) {
+      const int i = idx % nt, j = idx / nt;
+      double s2 = 0.0;
+      if (i < pc && nt + j < pc)
+        for (int sl = 0; sl < BL.splits_g; ++sl) s2 += gram_p[(size_t)sl * nbt * nbt + (size_t)(nt + j) * nbt + i];
+      g12[idx] = s2;
+      tout[(size_t)j * nbt + nt + i] = 0.0;   // lower-left block
+    }
+  }
   __syncthreads();
   for (int q = 0; q < kk; ++q) {
     if (tid < q) {
@@ -64,14 +86,16 @@ __global__ __launch_bounds__(256) void k_bt_tfactor(const double* __restrict__ t
     if (tid < q) {
       // T[0:q, q] = -tau * T[0:q, 0:q] * G[0:q, q]
       double s = 0.0;
-      for (int l = tid; l < q; ++l) s += T[tid + l * nbt] * gcol[l];
-      T[tid + q * nbt] = -tau * s;
+      for (int l = tid; l < q; ++l) s += T[tid + l * nt] * gcol[l];
+      T[tid + q * nt] = -tau * s;
     }
-    if (tid == q) T[q + q * nbt] = tau;
+    if (tid == q) T[q + q * nt] = tau;
     __syncthreads();
   }
-  double* tout = bt + BL.t + (size_t)p * nbt * nbt;
-  for (int idx = tid; idx < nbt * nbt; idx += blockDim.x) tout[idx] = T[idx];
+  for (int idx = tid; idx < nt * nt; idx += blockDim.x) {
+    const int i = idx % nt, j = idx / nt;
+    tout[(size_t)(h * nt + j) * nbt + h * nt + i] = T[idx];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bt_sum(double* __restrict__ bt_all, BtLayout BL, int splits, int ncols) {
@@ -106,6 +130,8 @@ size_t bt_slab_doubles(int n, BtLayout* out) {
   L.vc = 0;
   L.gram = take(npanels * L.splits_g * kNbt * kNbt);
   L.t = take(npanels * kNbt * kNbt);
+  L.g12 = take(npanels * kNbtT * kNbtT);
+  L.tx = take(npanels * kNbtT * kNbtT);
   L.w1 = take((long long)L.splits * kNbt * n);
   L.w2 = take((long long)kNbt * n);
   L.slab = off;
@@ -116,7 +142,7 @@ size_t bt_slab_doubles(int n, BtLayout* out) {
 int bt_desc_count(int n, int batch) {
   const int nref = std::max(n - 2, 0);
   const int npanels = (nref + kNbt - 1) / kNbt;
-  return npanels * 4 * batch;
+  return npanels * 6 * batch;
 }
 
 // d_a is modified (cleaned); d_vt: (batch, n, n) scratch that receives V T.
@@ -130,9 +156,10 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   const int npanels = (nref + nbt - 1) / nbt;
   const int w1s = std::min(BL.splits, w1_splits_for(ncols, batch));
 
-  // descriptor table: [gram | vt | w1 | update] x npanels x batch  (each group contiguous for one launch)
+  // descriptor table: [gram | vt | w1 | update | x = G12 T2 | T12 = -T1 x] x npanels x batch  (each group contiguous
+  // for one launch)
   const size_t grp = (size_t)npanels * batch;
-  std::vector<GemmDesc> h(4 * grp);
+  std::vector<GemmDesc> h(6 * grp);
   for (int p = 0; p < npanels; ++p) {
     const int cs = p * nbt;
     const int mrow = n - cs - off;
@@ -172,6 +199,22 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       U.m = mrow; U.n = ncols; U.k = pc;
       U.alpha = -1.0; U.beta = 1.0;
       h[3 * grp + (size_t)p * batch + b] = U;
+      double* g12 = bt + BL.g12 + (size_t)p * kNbtT * kNbtT;
+      double* tx = bt + BL.tx + (size_t)p * kNbtT * kNbtT;
+      GemmDesc X{};   // x = G12 T2
+      X.a = g12; X.sa_i = 1; X.sa_k = kNbtT;
+      X.b = tp + (size_t)kNbtT * nbt + kNbtT; X.sb_k = 1; X.sb_j = nbt;
+      X.c = tx; X.ldc = kNbtT;
+      X.m = kNbtT; X.n = kNbtT; X.k = kNbtT;
+      X.alpha = 1.0; X.beta = 0.0;
+      h[4 * grp + (size_t)p * batch + b] = X;
+      GemmDesc Y{};   // T12 = -T1 x
+      Y.a = tp; Y.sa_i = 1; Y.sa_k = nbt;
+      Y.b = tx; Y.sb_k = 1; Y.sb_j = kNbtT;
+      Y.c = tp + (size_t)kNbtT * nbt; Y.ldc = nbt;
+      Y.m = kNbtT; Y.n = kNbtT; Y.k = kNbtT;
+      Y.alpha = -1.0; Y.beta = 0.0;
+      h[5 * grp + (size_t)p * batch + b] = Y;
     }
   }
   SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
@@ -179,8 +222,10 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
                      nref, off);
   SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g, false, false, kGemmAkBk));
-  hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)npanels, (unsigned)batch), dim3(256),
-                     sizeof(double) * (nbt * nbt + nbt), st, d_tri_ws, TL, d_bt_ws, BL, nref);
+  hipLaunchKernelGGL(k_bt_tfactor, dim3((unsigned)(2 * npanels), (unsigned)batch), dim3(256),
+                     sizeof(double) * (kNbtT * kNbtT + kNbtT), st, d_tri_ws, TL, d_bt_ws, BL, nref);
+  SC_TRY(launch_gemm_f64(ctx, d_descs + 4 * grp, (int)grp, kNbtT, kNbtT, kGemmTile, 1, false, false, kGemmAmBk));
+  SC_TRY(launch_gemm_f64(ctx, d_descs + 5 * grp, (int)grp, kNbtT, kNbtT, kGemmTile, 1, false, false, kGemmAmBk));
   SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile, 1, false, false, kGemmAmBk));
 
   PhaseTimer t_w(ctx, "bt1_w", st), t_u(ctx, "bt1_update", st);

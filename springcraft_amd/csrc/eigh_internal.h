@@ -88,6 +88,8 @@ struct BtLayout {
   long long vc;     // (unused)
   long long gram;   // per block: split-K slabs of V^T V, splits_g x nbt x nbt
   long long t;      // per block: nbt x nbt triangular factor
+  long long g12;    // per block: summed Gram block V1^T V2 (128 x 128)
+  long long tx;     // per block: (V1^T V2) T2
   long long w1;     // split-K slabs of V^T Z: splits x nbt x n
   long long w2;     // T * sum(w1): nbt x n
   int splits_g;
