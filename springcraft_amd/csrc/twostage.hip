@@ -71,8 +71,12 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   // 8-column inner block, the other columns get the inner block's reflectors at once from k_pqr_blk_a / _b)
   constexpr int LD = kQrRows + 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* P = sm;                      // [kB][LD]   P[c * LD + r]
-  double* wv = sm + kB * LD;           // [kB]  w_c of the reflector being applied
+  // only the columns this launch touches, c_lo .. c_end-1, are held (the image is indexed relative to c_lo): with the
+  // blocked panels that is at most 9 columns = 9 KB instead of 66 KB, i.e. 8 workgroups per CU instead of 2
+  const int c_lo = j > 0 ? j - 1 : 0;
+  const int ncl = c_end - c_lo;
+  double* P = sm;                      // [ncl][LD]   column c at P[(c - c_lo) * LD + r]
+  double* wv = sm + ncl * LD;          // [kB]  w_c of the reflector being applied
   double* vv = wv + kB;                // [kQrRows]  v_r
   double* red = vv + kQrRows;          // [4][kB]
   __shared__ double s_scale, s_beta, s_tau;
@@ -86,7 +90,6 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   const int row_base = chunk * kQrRows;   // local (panel) row of this chunk's first row
   const int tid = threadIdx.x;
   const int prev = j - 1;
-  const int c_lo = j > 0 ? j - 1 : 0;
   // launch j reads what launch j-1 left and writes for launch j+1 while other workgroups may still be reading:
   // two copies, alternating
   const int nchunk_cap = (n + kQrRows - 1) / kQrRows + 1;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
       for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (c + 2 * u < c_end) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+        if (c + 2 * u < c_end) P[((c + 2 * u) - c_lo) * LD + r] = rl < m ? t[u] : 0.0;
     }
   }
   __syncthreads();
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     if (tid < kQrRows) {
       const int rl = row_base + tid;
       double v = 0.0;
-      if (rl < m) v = rl > prev ? s_scale * P[prev * LD + tid] : (rl == prev ? 1.0 : 0.0);
+      if (rl < m) v = rl > prev ? s_scale * P[(prev - c_lo) * LD + tid] : (rl == prev ? 1.0 : 0.0);
       vv[tid] = v;
     }
     __syncthreads();
@@ -159,15 +162,15 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     if (c >= j && c < c_end) {
       const double w = wv[c];
 #pragma unroll 8
-      for (int r = q * 32; r < q * 32 + 32; ++r) P[c * LD + r] -= vv[r] * w;
+      for (int r = q * 32; r < q * 32 + 32; ++r) P[(c - c_lo) * LD + r] -= vv[r] * w;
     }
     // column prev: v below the pivot, beta at it (rows above keep their R entries); and the panel buffers
     if (tid < kQrRows) {
       const int rl = row_base + tid;
       if (rl < m) {
         const double v = vv[tid];
-        if (rl > prev) P[prev * LD + tid] = v;
-        else if (rl == prev) P[prev * LD + tid] = s_beta;
+        if (rl > prev) P[(prev - c_lo) * LD + tid] = v;
+        else if (rl == prev) P[(prev - c_lo) * LD + tid] = s_beta;
         const size_t row = (size_t)r0 + rl;
         sb[SL.vw + (size_t)prev * n + row] = v;
         sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
@@ -184,14 +187,14 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
 #pragma unroll 8
       for (int r = q * 32; r < q * 32 + 32; ++r) {
         const int rl = row_base + r;
-        if (rl > j && rl < m) acc += P[j * LD + r] * P[c * LD + r];
+        if (rl > j && rl < m) acc += P[(j - c_lo) * LD + r] * P[(c - c_lo) * LD + r];
       }
     }
     red[q * kB + c] = acc;
     __syncthreads();
     if (tid < kB) {
       part_out[(size_t)chunk * kB + tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
-      if (chunk == 0 && tid >= j && tid < c_end) piv_out[tid] = P[tid * LD + j];   // pivot row (alpha at [j])
+      if (chunk == 0 && tid >= j && tid < c_end) piv_out[tid] = P[(tid - c_lo) * LD + j];   // pivot row (alpha at [j])
     }
   } else {
     // last launch of the panel: columns without a reflector (short last panel) are zero in the V buffers
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
     const int r = tid & (kQrRows - 1), half = tid >> 7;
     const int rl = row_base + r;
     if (rl < m)
-      for (int cc = c_lo + half; cc < c_end; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
+      for (int cc = c_lo + half; cc < c_end; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[(cc - c_lo) * LD + r];
   }
 }
 
@@ -229,8 +232,8 @@ __device__ __forceinline__ void blk_explicit_v(double* P, int LD, int c0, int nc
   for (int idx = threadIdx.x; idx < ncols * kB; idx += 256) {
     const int i = idx / kB, r = idx % kB;   // rows 0..63 suffice (pivots < 64)
     const int piv = c0 + i;
-    if (r < piv) P[(c0 + i) * LD + r] = 0.0;
-    else if (r == piv) P[(c0 + i) * LD + r] = 1.0;
+    if (r < piv) P[i * LD + r] = 0.0;          // (the LDS image starts at column c0)
+    else if (r == piv) P[i * LD + r] = 1.0;
   }
 }
 
@@ -239,8 +242,8 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
                                                    double* __restrict__ sb_all, SbLayout SL, int j0, int c0) {
   constexpr int LD = kQrRows + 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* P = sm;                      // [kB][LD]
-  double* vv = sm + kB * LD;           // [kQrRows]
+  double* P = sm;                      // [kB - c0][LD]: columns c0 .. kB-1, indexed relative to c0
+  double* vv = sm + (kB - c0) * LD;    // [kQrRows]
   double* red = vv + kQrRows;          // [4][2][kB]
   __shared__ double s_scale, s_beta, s_tau;
   const int n = TL.n;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
       for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+        if (c + 2 * u < kB) P[((c + 2 * u) - c0) * LD + r] = rl < m ? t[u] : 0.0;
     }
   }
   __syncthreads();
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
   if (tid < kQrRows) {
     const int rl = row_base + tid;
     double v = 0.0;
-    if (rl < m) v = rl > prev ? s_scale * P[prev * LD + tid] : (rl == prev ? 1.0 : 0.0);
+    if (rl < m) v = rl > prev ? s_scale * P[(prev - c0) * LD + tid] : (rl == prev ? 1.0 : 0.0);
     if (rl < m) {
       if (rl > prev) A[(size_t)(j0 + prev) * n + r0 + rl] = v;
       else if (rl == prev) A[(size_t)(j0 + prev) * n + r0 + rl] = s_beta;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
       sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
       sb[SL.xv + (size_t)(2 * kB + prev) * n + row] = v;
     }
-    P[prev * LD + tid] = v;
+    P[(prev - c0) * LD + tid] = v;
   }
   __syncthreads();
   blk_explicit_v(P, LD, c0, kIb - 1, row_base);
@@ -310,9 +313,9 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
   if (c >= c0) {
 #pragma unroll 4
     for (int r = q * 32; r < q * 32 + 32; ++r) {
-      const double x = P[c * LD + r];
+      const double x = P[(c - c0) * LD + r];
 #pragma unroll
-      for (int i = 0; i < kIb; ++i) acc[i] += P[(c0 + i) * LD + r] * x;
+      for (int i = 0; i < kIb; ++i) acc[i] += P[((c0 + i) - c0) * LD + r] * x;
     }
   }
   double* p8 = sb + SL.qrpart8 + (size_t)chunk * kIb * kB;
@@ -335,8 +338,8 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
                                                    double* __restrict__ sb_all, SbLayout SL, int j0, int c0) {
   constexpr int LD = kQrRows + 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* P = sm;                      // [kB][LD]
-  double* Ms = sm + kB * LD;           // [kIb][kB]  M, later W
+  double* P = sm;                      // [kB - c0][LD]: columns c0 .. kB-1, indexed relative to c0
+  double* Ms = sm + (kB - c0) * LD;    // [kIb][kB]  M, later W
   double* red = Ms + kIb * kB;         // [4][kB]
   __shared__ double T[kIb][kIb];
   const int n = TL.n;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
       for (int u = 0; u < 8; ++u) t[u] = src[(size_t)std::min(c + 2 * u, kB - 1) * n];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (c + 2 * u < kB) P[(c + 2 * u) * LD + r] = rl < m ? t[u] : 0.0;
+        if (c + 2 * u < kB) P[((c + 2 * u) - c0) * LD + r] = rl < m ? t[u] : 0.0;
     }
   }
   // M = sum of the chunks' partial products
@@ -423,8 +426,8 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
     for (int r = q * 32; r < q * 32 + 32; ++r) {
       double s2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < kIb; ++i) s2 += P[(c0 + i) * LD + r] * wcol[i];
-      P[c * LD + r] -= s2;
+      for (int i = 0; i < kIb; ++i) s2 += P[((c0 + i) - c0) * LD + r] * wcol[i];
+      P[(c - c0) * LD + r] -= s2;
     }
   }
   __syncthreads();
@@ -435,14 +438,14 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
 #pragma unroll 8
       for (int r = q * 32; r < q * 32 + 32; ++r) {
         const int rl = row_base + r;
-        if (rl > jn && rl < m) acc += P[jn * LD + r] * P[c * LD + r];
+        if (rl > jn && rl < m) acc += P[(jn - c0) * LD + r] * P[(c - c0) * LD + r];
       }
     }
     red[q * kB + c] = acc;
     __syncthreads();
     if (tid < kB) {
       part_out[(size_t)chunk * kB + tid] = (red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]);
-      if (chunk == 0 && tid >= jn && tid < jn + kIb) piv_out[tid] = P[tid * LD + jn];
+      if (chunk == 0 && tid >= jn && tid < jn + kIb) piv_out[tid] = P[(tid - c0) * LD + jn];
     }
   }
   // LDS -> chunk (columns to the right of the inner block)
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
     const int r = tid & (kQrRows - 1), half = tid >> 7;
     const int rl = row_base + r;
     if (rl < m)
-      for (int cc = jn + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[cc * LD + r];
+      for (int cc = jn + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[(cc - c0) * LD + r];
   }
 }
 
@@ -1530,6 +1533,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * TL.slab + TL.tau, 0, sizeof(double) * n, st));
 
   const size_t lds_qr = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kB + kQrRows + 4 * kB);
+  const size_t lds_qr_blk = sizeof(double) * ((size_t)(kIb + 1) * (kQrRows + 1) + kB + kQrRows + 4 * kB);
   const size_t lds_small = sizeof(double) * 4 * kB * (kB + 1);
   const size_t lds_blk_a = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kQrRows + 8 * kB);
   const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
@@ -1543,16 +1547,19 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     t_qr.start();
     if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
-      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, 0, nr,
-                         kIb);
+      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, 0,
+                         nr, kIb);
       for (int c0 = 0; c0 < kB; c0 += kIb) {
         for (int j = c0 + 1; j < c0 + kIb; ++j)
-          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, j,
-                             nr, c0 + kIb);
-        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, c0);
+          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
+                             j, nr, c0 + kIb);
+        // (their LDS image holds columns c0 .. kB-1 only)
+        const size_t cut = sizeof(double) * (size_t)c0 * (kQrRows + 1);
+        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a - cut, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
+                           c0);
         if (c0 + kIb < kB)
-          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
-                             c0);
+          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b - cut, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL,
+                             j0, c0);
       }
     } else {
       for (int j = 0; j <= nr; ++j)
