@@ -218,7 +218,7 @@ def run_c3(args, rank, world, torch, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -342,18 +342,21 @@ def run_c4(args, rank, world, torch, dist):
         w, _ = solve_sharded(coords, ff, dim=3, want_vectors=True, solver=solver)
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # every rank checks its own shard: residual + orthogonality of its first and last structure (device arithmetic)
     h_all = solver.assemble(solver.last_coord)
     worst = torch.zeros(2, dtype=torch.float64, device="cuda")
+    
     eye = torch.eye(3 * n_atoms, dtype=torch.float64, device="cuda")
     for b in sorted(set([0, hi - lo - 1])):
         hb, wb, vb = h_all[b], solver.w[b], solver.v[b]
         r = hb @ vb.T - vb.T * wb[None, :]
         worst[0] = max(worst[0], torch.linalg.vector_norm(r, dim=0).max() / wb.abs().max())
         worst[1] = max(worst[1], (vb @ vb.T - eye).abs().max())
+    worst = worst.to(cdev)
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     out = None
     if rank == 0:
@@ -425,11 +428,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: springcraft_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU.  Rehearsal on a box with fewer GPUs than ranks (tests / the 1-GPU development box):
+    # SPRINGCRAFT_BENCH_SHARE_GPUS=1 maps rank r to device r % device_count and uses gloo (RCCL refuses two ranks on
+    # one device); never set by the driver.
+    share = os.environ.get("SPRINGCRAFT_BENCH_SHARE_GPUS") == "1"
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not share:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {ndev} visible)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1 or args.config == "c4":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share and world > ndev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
 
     out = (run_c4 if args.config == "c4" else run_c3)(args, rank, world, torch, dist)
     if rank == 0:

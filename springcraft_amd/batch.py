@@ -161,8 +161,9 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
             elif (solver.n_atoms, solver.batch, solver.dim) != (n_atoms, nloc, dim):
                 raise ValueError(f"solver was built for {(solver.n_atoms, solver.batch, solver.dim)}, "
                                  f"this rank's shard is {(n_atoms, nloc, dim)}")
-            w, v_local = solver.solve(local[:nloc].contiguous())
-            w_local[:nloc] = w
+            # (with a CPU backend such as gloo the shards travel as CPU tensors: onto the solver's GPU and back)
+            w, v_local = solver.solve(local[:nloc].to(solver.device).contiguous())
+            w_local[:nloc] = w.to(dev)
         else:
             w_np, v_local = solver_factory(n_atoms, nloc)(local[:nloc].cpu().numpy())
             w_local[:nloc] = torch.from_numpy(np.asarray(w_np)).to(dev)

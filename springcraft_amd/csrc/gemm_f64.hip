@@ -266,6 +266,14 @@ struct StageImage {
   }
 };
 
+// Diagnostic build (-DGEMM_STAMPS): shader cycles of the prologue / K loop / epilogue of every wave, summed
+// (sc_dbg_gemm_stamps, tools/gemm_stamps.py); no stamp executes in the normal build.
+#ifdef GEMM_STAMPS
+__device__ unsigned long long g_gemm_stamps[8];
+#define GEMM_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#else
+#define GEMM_STAMP(var)
+#endif
 typedef const double __attribute__((address_space(1)))* gptr_c;   // loads through these are global_load, not flat_load
 typedef double __attribute__((address_space(1)))* gptr;             // (a flat access also counts on lgkmcnt: the barrier's wait would wait for it)
 
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
   if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
 
+  GEMM_STAMP(t_start)
   int k_begin = 0, k_end = K;
   if (split_k > 1) {
     const int chunk = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
@@ -487,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   // K loop.  Iteration t: the registers hold K step t + 1 (loaded one MFMA run ago): write them to the other buffer
   // (all waves left it at the barrier that ended iteration t - 1), re-issue the loads for K step t + 2, then the MFMA
   // run of K step t with the fragments of k4 + 1 read while the MFMAs of k4 issue.
+  GEMM_STAMP(t_loop)
   int buf = 0;
   for (int kt = k_begin; kt < k_end; kt += BK) {
     if (kt + BK < k_end) s_write(buf ^ 1, kt + BK);
@@ -517,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
     buf ^= 1;
   }
 
+  GEMM_STAMP(t_epi)
   // ---- epilogue (store only)
 #pragma unroll
   for (int ni = 0; ni < NT; ++ni) {
@@ -534,6 +545,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
       }
     }
   }
+#ifdef GEMM_STAMPS
+  {
+    GEMM_STAMP(t_end)
+    if (lane == 0) {
+      atomicAdd(&g_gemm_stamps[0], t_loop - t_start);
+      atomicAdd(&g_gemm_stamps[1], t_epi - t_loop);
+      atomicAdd(&g_gemm_stamps[2], t_end - t_epi);
+      atomicAdd(&g_gemm_stamps[3], 1ull);
+    }
+  }
+#endif
 }
 
 // One instantiation per (block tile, layout, triangular A); its dynamic LDS size is raised above the 64 KB default once.
@@ -654,6 +676,20 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
+}
+
+extern "C" int sc_dbg_gemm_stamps(unsigned long long* out4, int reset) {
+#ifdef GEMM_STAMPS
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_gemm_stamps), 32) != hipSuccess) return 5;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, 64) != hipSuccess) return 5;
+  }
+  return 0;
+#else
+  (void)out4; (void)reset;
+  return 1;
+#endif
 }
 
 // ---- debug / tuning entry point (not part of the public C ABI) ----------------------------------------------
