@@ -1,0 +1,40 @@
+/*
+ * springcraft_hip_debug.h -- tuning / diagnostic entry points of libspringcraft_hip.so.
+ *
+ * NOT part of the drop-in boundary (that is springcraft_hip.h): nothing in the product path calls these; they exist for
+ * the scripts under tools/ and may change between rounds.  They are exported from the same library so that the kernels
+ * they exercise are exactly the ones the product launches.
+ */
+#ifndef SPRINGCRAFT_HIP_DEBUG_H
+#define SPRINGCRAFT_HIP_DEBUG_H
+
+#include "springcraft_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Times `iters` launches of one grouped-GEMM shape on buffers it allocates itself and checks the result against a host
+ * product (max abs error).  mode 0: C = A B (A m x k, B k x n, column-major); 1: lower triangle of C += A B^T (the
+ * SYR2K shape, B stored n x k); 2: C = A^T B (A stored k x m).  tile 0..3 pick the round-1 kernel's tilings,
+ * 10..13 the k_gemm2 tilings (64x64, 128x64, 128x128, automatic).  Returns an SC_* code.  tools/gemm2_bench.py */
+int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int split_k, int iters, int beta_one,
+                      double* ms_out, double* max_err_out);
+
+/* s_memtime segment sums of k_gemm2 (library built with -DGEMM_STAMPS; returns 1 otherwise): out4[0..2] =
+ * shader cycles summed over waves in the prologue, the K loop and the C epilogue, out4[3] = waves counted; `reset`
+ * zeroes the sums after the read.  tools/gemm_stamps.py */
+int sc_dbg_gemm_stamps(unsigned long long* out4, int reset);
+
+/* Band (128 x n, AB(i,j) at [(i-j) + 128 j]) after stage 1 and the tridiagonal (d, e) after stage 2 of ONE host matrix
+ * (n x n, NumPy layout, lower triangle read; n >= 256).  tools/check_two_stage.py */
+int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* band_out, double* d_out, double* e_out);
+
+/* Per-wave s_memtime segment sums of k_bt2_apply (library built with -DBT2_STAMPS; returns 1 otherwise):
+ * out[64 workgroups][8 waves][8 sums + diamond count].  tools/bt2_stamps.py */
+int sc_dbg_bt2_stamps(unsigned long long* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

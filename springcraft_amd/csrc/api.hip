@@ -47,6 +47,19 @@ int sc_reserve_scratch(sc_ctx* ctx, size_t bytes) {
   return SC_OK;
 }
 
+int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->dc_aux_bytes) return SC_OK;
+  if (ctx->dc_aux) {
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipFree(ctx->dc_aux));
+    ctx->dc_aux = nullptr;
+    ctx->dc_aux_bytes = 0;
+  }
+  SC_HIP(ctx, hipMalloc(&ctx->dc_aux, bytes));
+  ctx->dc_aux_bytes = bytes;
+  return SC_OK;
+}
+
 int sc_aux_stream(sc_ctx* ctx) {
   if (ctx->aux_stream) return SC_OK;
   SC_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -309,6 +322,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->dc_aux) (void)hipFree(ctx->dc_aux);
   if (ctx->aux_stream) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->aux_stream);

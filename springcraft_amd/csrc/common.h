@@ -29,6 +29,10 @@ struct sc_ctx {
   // small cached scratch for the assembly entry points (patch tables, counts, ...)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // node tables / oversize-merge copies of the divide-and-conquer solver (lives across a whole eigensolve, so it
+  // cannot share `scratch`, which the assembly entry points hold while they call the solver)
+  void* dc_aux = nullptr;
+  size_t dc_aux_bytes = 0;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
   bool profiling = false;
@@ -94,6 +98,7 @@ int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);
 int sc_reserve_ws(sc_ctx* ctx, size_t bytes);
 int sc_aux_stream(sc_ctx* ctx);   // creates aux_stream / aux_fork / aux_join if needed
 int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
+int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

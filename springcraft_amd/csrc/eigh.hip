@@ -397,13 +397,15 @@ __global__ void k_pinv_scale(const double* __restrict__ q, const double* __restr
 int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_out) {
   const int n = (int)n64;
   hipStream_t st = ctx->stream;
-  // buffers: w (n) | Q (n^2) | QS (n^2) | desc, carved from the scratch allocation behind d_out's caller
-  double *d_w, *d_q, *d_qs;
-  GemmDesc* d_desc;
-  SC_HIP(ctx, hipMalloc(&d_w, sizeof(double) * n));
-  SC_HIP(ctx, hipMalloc(&d_q, sizeof(double) * (size_t)n * n));
-  SC_HIP(ctx, hipMalloc(&d_qs, sizeof(double) * (size_t)n * n));
-  SC_HIP(ctx, hipMalloc(&d_desc, sizeof(GemmDesc)));
+  // buffers: Q (n^2) | QS (n^2) | w (n) | desc -- one allocation, so a failed one leaves nothing behind (the
+  // context's cached buffers are all in use by the caller and by eigh_batched while this runs)
+  const size_t nn = align_up(sizeof(double) * (size_t)n * n, 256), nw = align_up(sizeof(double) * (size_t)n, 256);
+  char* d_base = nullptr;
+  SC_HIP(ctx, hipMalloc((void**)&d_base, 2 * nn + nw + sizeof(GemmDesc)));
+  double* d_q = reinterpret_cast<double*>(d_base);
+  double* d_qs = reinterpret_cast<double*>(d_base + nn);
+  double* d_w = reinterpret_cast<double*>(d_base + 2 * nn);
+  GemmDesc* d_desc = reinterpret_cast<GemmDesc*>(d_base + 2 * nn + nw);
   int rc = eigh_batched(ctx, d_a, n, 1, d_w, d_q);
   if (rc == SC_OK) {
     hipLaunchKernelGGL(k_pinv_scale, dim3((unsigned)n), dim3(256), 0, st, d_q, d_w, n, rcond, d_qs);
@@ -416,6 +418,6 @@ int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_
     if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile, 1, false, false, kGemmAmBn);
     if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;
   }
-  (void)hipFree(d_w); (void)hipFree(d_q); (void)hipFree(d_qs); (void)hipFree(d_desc);
+  (void)hipFree(d_base);
   return rc;
 }

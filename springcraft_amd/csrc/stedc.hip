@@ -712,12 +712,13 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     flat.insert(flat.end(), tree.levels[l].begin(), tree.levels[l].end());
   }
   const size_t n_internal = flat.size() - tree.leaves.size();
-  // scratch for node tables + fail flag + oversize-merge scratch lives at the tail of the desc buffer's owner:
-  DcNode* d_nodes = nullptr;
-  int* d_fail = nullptr;
+  // node tables + fail flag + the sorted copies of oversize merges: one cached allocation of the context
   const size_t node_bytes = align_up(flat.size() * sizeof(DcNode), 256);
-  SC_HIP(ctx, hipMalloc((void**)&d_nodes, node_bytes + 256));
-  d_fail = reinterpret_cast<int*>(reinterpret_cast<char*>(d_nodes) + node_bytes);
+  const size_t big_bytes = n > kLdsCapSetup ? (size_t)batch * 3 * n * sizeof(double) : 0;
+  SC_TRY(sc_reserve_dc_aux(ctx, node_bytes + 256 + big_bytes));
+  DcNode* d_nodes = reinterpret_cast<DcNode*>(ctx->dc_aux);
+  int* d_fail = reinterpret_cast<int*>(reinterpret_cast<char*>(d_nodes) + node_bytes);
+  double* d_big = big_bytes ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_nodes) + node_bytes + 256) : nullptr;
   SC_HIP(ctx, hipMemcpyAsync(d_nodes, flat.data(), flat.size() * sizeof(DcNode), hipMemcpyHostToDevice, st));
   SC_HIP(ctx, hipMemsetAsync(d_fail, 0, sizeof(int), st));
 
@@ -762,10 +763,6 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                      d_nodes + tree.leaves.size(), (int)n_internal);
   hipLaunchKernelGGL((k_dc_leaves<kLeafMax>), dim3((unsigned)tree.leaves.size(), (unsigned)batch), dim3(64),
                      0, st, d_dc_ws, DL, d_nodes, qbuf(0), stride_q, d_fail);
-
-  // oversize merges keep their sorted copies in global memory
-  double* d_big = nullptr;
-  if (n > kLdsCapSetup) SC_HIP(ctx, hipMalloc((void**)&d_big, (size_t)batch * 3 * n * sizeof(double)));
 
   PhaseTimer t_gemm(ctx, "dc_gemm", st);
   for (int l = 0; l < nlev; ++l) {
@@ -823,8 +820,6 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   SC_HIP(ctx, hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
   SC_HIP(ctx, hipStreamSynchronize(st));  // also keeps flat / h_descs alive until the copies are done
   t_gemm.finish();
-  if (d_big) SC_HIP(ctx, hipFree(d_big));
-  SC_HIP(ctx, hipFree(d_nodes));
   if (h_fail) return sc_set_error(ctx, SC_ERR_NOCONV, "tridiagonal QL iteration did not converge");
   return SC_OK;
 }

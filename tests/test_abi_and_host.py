@@ -24,6 +24,22 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_debug_header_matches_library():
+    """Every sc_dbg_* symbol the library exports is declared in include/springcraft_hip_debug.h and vice versa."""
+    import subprocess
+    from springcraft_amd import _hip
+
+    header = open(join(ROOT, "include", "springcraft_hip_debug.h")).read()
+    declared = set(re.findall(r"\b(sc_dbg_[a-z0-9_]+)\s*\(", header))
+    out = subprocess.run(["nm", "-D", "--defined-only", _hip.library_path()], capture_output=True, text=True,
+                         check=True).stdout
+    exported = set(re.findall(r"\bT (sc_dbg_[a-z0-9_]+)$", out, re.M))
+    assert declared == exported
+    # and the boundary header declares everything else the library exports under the sc_ prefix
+    public = set(re.findall(r"\bT (sc_[a-z0-9_]+)$", out, re.M)) - exported
+    assert public == set(_hip.EXPORTED_SYMBOLS)
+
+
 def test_no_cpu_fallback():
     import torch
 
