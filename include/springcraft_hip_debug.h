@@ -17,7 +17,7 @@ extern "C" {
 /* Times `iters` launches of one grouped-GEMM shape on buffers it allocates itself and checks the result against a host
  * product (max abs error).  mode 0: C = A B (A m x k, B k x n, column-major); 1: lower triangle of C += A B^T (the
  * SYR2K shape, B stored n x k); 2: C = A^T B (A stored k x m).  tile 0..3 pick the round-1 kernel's tilings,
- * 10..13 the k_gemm2 tilings (64x64, 128x64, 128x128, automatic).  Returns an SC_* code.  tools/gemm2_bench.py */
+ * 10..13 the k_gemm2 tilings (automatic, 128x128, 128x64, 64x64).  Returns an SC_* code.  tools/gemm2_bench.py */
 int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int split_k, int iters, int beta_one,
                       double* ms_out, double* max_err_out);
 
@@ -25,6 +25,11 @@ int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int 
  * shader cycles summed over waves in the prologue, the K loop and the C epilogue, out4[3] = waves counted; `reset`
  * zeroes the sums after the read.  tools/gemm_stamps.py */
 int sc_dbg_gemm_stamps(unsigned long long* out4, int reset);
+
+/* Per-workgroup timeline of k_gemm2 (same diagnostic build): up to `max_records` records of 6 values
+ * {hw id (XCC_ID << 32 | HW_ID), t_start, t_loop, t_epilogue, t_end, blockIdx linear} of the workgroups launched since
+ * the last reset; returns the number of records written through *count.  tools/gemm_trace.py */
+int sc_dbg_gemm_trace(unsigned long long* out, int max_records, int* count, int reset);
 
 /* Band (128 x n, AB(i,j) at [(i-j) + 128 j]) after stage 1 and the tridiagonal (d, e) after stage 2 of ONE host matrix
  * (n x n, NumPy layout, lower triangle read; n >= 256).  tools/check_two_stage.py */

@@ -65,7 +65,7 @@ class DeviceBatchSolver:
         self.ctx.check(self._L.sc_last_eigh_timings(self.ctx.handle, t))
         out = {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2]}
         if t[5] > 0:   # two-stage tridiagonalisation
-            out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_fused_ms=t[5])
+            out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_apply_ms=t[5])
             for name in ("panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update"):
                 ms = C.c_double(0.0)
                 if self._L.sc_last_eigh_phase_ms(self.ctx.handle, name.encode(), C.byref(ms)) == 0:

@@ -270,6 +270,9 @@ struct StageImage {
 // (sc_dbg_gemm_stamps, tools/gemm_stamps.py); no stamp executes in the normal build.
 #ifdef GEMM_STAMPS
 __device__ unsigned long long g_gemm_stamps[8];
+constexpr int kTraceMax = 1 << 16;
+__device__ unsigned long long g_gemm_trace[6 * kTraceMax];
+__device__ unsigned int g_gemm_trace_n;
 #define GEMM_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
 #else
 #define GEMM_STAMP(var)
@@ -554,6 +557,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
       atomicAdd(&g_gemm_stamps[2], t_end - t_epi);
       atomicAdd(&g_gemm_stamps[3], 1ull);
     }
+    if (tid == 0) {
+      const unsigned slot = atomicAdd(&g_gemm_trace_n, 1u);
+      if (slot < (unsigned)kTraceMax) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* r = g_gemm_trace + 6ull * slot;
+        r[0] = ((unsigned long long)xcc << 32) | hwid;
+        r[1] = t_start; r[2] = t_loop; r[3] = t_epi; r[4] = t_end;
+        r[5] = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+      }
+    }
   }
 #endif
 }
@@ -688,6 +703,24 @@ extern "C" int sc_dbg_gemm_stamps(unsigned long long* out4, int reset) {
   return 0;
 #else
   (void)out4; (void)reset;
+  return 1;
+#endif
+}
+
+extern "C" int sc_dbg_gemm_trace(unsigned long long* out, int max_records, int* count, int reset) {
+#ifdef GEMM_STAMPS
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_gemm_trace_n), 4) != hipSuccess) return 5;
+  const int m = (int)std::min<unsigned>(std::min<unsigned>(n, (unsigned)kTraceMax), (unsigned)std::max(0, max_records));
+  if (m > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), (size_t)m * 48) != hipSuccess) return 5;
+  if (count) *count = m;
+  if (reset) {
+    n = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace_n), &n, 4) != hipSuccess) return 5;
+  }
+  return 0;
+#else
+  (void)out; (void)max_records; (void)count; (void)reset;
   return 1;
 #endif
 }

@@ -6,7 +6,8 @@
 //           wave instruction = 4 columns x 128 B
 //   row16   16 B per lane, 8 lanes per 128-B column segment: one wave instruction = 8 columns x 128 B
 //   row16x  the same, a whole 1 KB column (128 rows) per 64 lanes: one wave instruction = 1 column x 1 KB
-// in the variants  r (read only), w (write only), rw (read, then write after all reads of the tile have landed).
+// in the variants  r (read only), w (write only), rw (read, then write after all reads of the tile have landed) and, for
+// mfma8, global_atomic_add_f64 without return (the memory side does the read-modify-write; counted as rw bytes).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(double* __restrict__ a, int n, 
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           double* p = C + (size_t)(wn * 64 + ni * 16 + fk + 4 * r) * n + wm * 64 + mi * 16 + fr;
-          v[ni][r][mi] = MODE == 1 ? 1.0 : *p;
+          v[ni][r][mi] = (MODE == 1 || MODE == 3) ? 1.0 : *p;
         }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(256, 2) void k_tile(double* __restrict__ a, int n, 
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           double* p = C + (size_t)(wn * 64 + ni * 16 + fk + 4 * r) * n + wm * 64 + mi * 16 + fr;
-          if (MODE == 0) s += v[ni][r][mi]; else *p = v[ni][r][mi] + 1.0;
+          if (MODE == 0) s += v[ni][r][mi];
+          else if (MODE == 3) (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v[ni][r][mi]);
+          else *p = v[ni][r][mi] + 1.0;
         }
   } else if (MAP == 1) {
     // wave w: columns 32 w .. 32 w + 31; instruction: 8 columns x 16 rows; lane: column l >> 3, rows 2 (l & 7), + 1
@@ -87,8 +90,8 @@ static void run(const char* name, double* a, int n, int batch, double* sink) {
   for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((k_tile<MAP, MODE>), grid, dim3(256), 0, 0, a, n, tpd, (long long)n * n, sink);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
-  const double bytes = (double)tpd * tpd * batch * 128 * 128 * 8 * (MODE == 2 ? 2 : 1);
-  printf("%-10s %8.3f ms  %6.2f TB/s\n", name, ms, bytes / ms * 1e-9);
+  const double bytes = (double)tpd * tpd * batch * 128 * 128 * 8 * (MODE >= 2 ? 2 : 1);
+  printf("%-34s %8.3f ms  %6.2f TB/s\n", name, ms, bytes / ms * 1e-9);
 }
 
 int main() {
@@ -97,6 +100,7 @@ int main() {
   CK(hipMalloc(&a, (size_t)n * n * batch * 8)); CK(hipMalloc(&sink, 64));
   CK(hipMemset(a, 0, (size_t)n * n * batch * 8));
   run<0, 0>("mfma8 r", a, n, batch, sink); run<0, 1>("mfma8 w", a, n, batch, sink); run<0, 2>("mfma8 rw", a, n, batch, sink);
+  run<0, 3>("mfma8 atomic add (counted as rw)", a, n, batch, sink);
   run<1, 0>("row16 r", a, n, batch, sink); run<1, 1>("row16 w", a, n, batch, sink); run<1, 2>("row16 rw", a, n, batch, sink);
   run<2, 0>("row16x r", a, n, batch, sink); run<2, 1>("row16x w", a, n, batch, sink); run<2, 2>("row16x rw", a, n, batch, sink);
   return 0;
