@@ -39,6 +39,11 @@ int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* band_out, doub
  * out[64 workgroups][8 waves][8 sums + diamond count].  tools/bt2_stamps.py */
 int sc_dbg_bt2_stamps(unsigned long long* out);
 
+/* s_memtime sums of k_bulge_step over all tasks since the last call (library built with -DBULGE_STAMPS; returns 1
+ * otherwise): out6 = {cycles from task start until the off-diagonal block E is in LDS, until E is stored [both: tasks
+ * with k > 0], until the diagonal block D is in LDS, until the end; tasks; tasks with k > 0}.  tools/bulge_stamps.py */
+int sc_dbg_bulge_stamps(unsigned long long* out6);
+
 #ifdef __cplusplus
 }
 #endif

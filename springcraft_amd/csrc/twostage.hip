@@ -49,6 +49,11 @@ __device__ __forceinline__ HH householder(double alpha, double xn2) {
   return h;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. waits for
+// the acknowledgement of every global store in flight (about 2 us under load) -- wasted when no thread of the workgroup
+// reads global data that another one wrote in the same kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -553,6 +558,15 @@ __global__ __launch_bounds__(256) void k_sb_clean(double* __restrict__ a_all, lo
 // Number of chase positions of sweep s: blocks of kB rows from row s+1 to n-1
 __host__ __device__ inline int chase_len(int n, int s) { return (n - 1 - s + kB - 1) / kB; }
 
+// Diagnostic build (-DBULGE_STAMPS): shader cycles of wave 0 between five points of every task, summed over all tasks
+// since the last read (sc_dbg_bulge_stamps, tools/bulge_stamps.py); no stamp executes in the normal build.
+#ifdef BULGE_STAMPS
+__device__ unsigned long long g_bulge_stamps[8];
+#define BULGE_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#else
+#define BULGE_STAMP(var)
+#endif
+
 // Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
 __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
                                                     int t) {
@@ -578,6 +592,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 
   const int r0 = s + 1 + k * kB;             // first row of the reflector being generated
   const int L = std::min(kB, n - r0);        // its length (>= 1)
+  BULGE_STAMP(t0)
 
   // the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored) is not touched before its own update:
   // fetch it right away (unconditional loads with clamped indices, masked when they go to LDS)
@@ -606,7 +621,10 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 #pragma unroll
       for (int u = 0; u < 16; ++u) E[i * LD + q * 16 + u] = i < L ? t16[u] : 0.0;
     }
-    __syncthreads();
+    lds_barrier();
+#ifdef BULGE_STAMPS
+    { BULGE_STAMP(t1) if (tid == 0) atomicAdd(&g_bulge_stamps[0], t1 - t0); }
+#endif
     // u = E vp
     {
       double a = 0.0;
@@ -614,12 +632,12 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += E[i * LD + jj] * vp[jj];
       red[q * kB + i] = a;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < kB) u[tid] = tau_p * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int jj = q * 16; jj < q * 16 + 16; ++jj) E[i * LD + jj] -= u[i] * vp[jj];
-    __syncthreads();
+    lds_barrier();
     // new reflector from the first column of E
     if (tid < 64) {
       const double x = E[tid * LD];
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       vn[tid] = tid == 0 ? 1.0 : (tid < L ? x * h.scale : 0.0);
       if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
     }
-    __syncthreads();
+    lds_barrier();
     // z_j = sum_i E[i, j] v_i  (j >= 1);  thread (j = i, rows q*16..)
     {
       double a = 0.0;
@@ -636,16 +654,19 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       for (int ii = q * 16; ii < q * 16 + 16; ++ii) a += E[ii * LD + i] * vn[ii];
       red[q * kB + i] = a;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
-    __syncthreads();
+    lds_barrier();
     // E <- H E, first column = beta e1; write back
     for (int jj = q * 16; jj < q * 16 + 16; ++jj) {
       double e = E[i * LD + jj] - vn[i] * u[jj];
       if (jj == 0) e = i == 0 ? s_beta : 0.0;
       if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
     }
-    __syncthreads();   // D reuses E's buffer
+    lds_barrier();   // D reuses E's buffer
+#ifdef BULGE_STAMPS
+    { BULGE_STAMP(t2) if (tid == 0) { atomicAdd(&g_bulge_stamps[1], t2 - t0); atomicAdd(&g_bulge_stamps[5], 1ull); } }
+#endif
   } else {
     // sweep start: x = AB(s+1 .. s+L, s)
     if (tid < 64) {
@@ -658,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
       if (tid < L) ab[(size_t)(1 + tid) + (size_t)s * kLdab] = tid == 0 ? h.beta : 0.0;
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // two-sided update of the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored)
@@ -671,21 +692,22 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       D[jj * LD + i] = x;
     }
   }
-  __syncthreads();
+  lds_barrier();
+  BULGE_STAMP(t3)
   {
     double a = 0.0;
 #pragma unroll
     for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += D[i * LD + jj] * vn[jj];
     red[q * kB + i] = a;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     const double p = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
     const double dot = wave_sum(p * vn[tid]);
     const double alpha2 = -0.5 * s_tau * dot;
     u[tid] = p + alpha2 * vn[tid];   // w
   }
-  __syncthreads();
+  lds_barrier();
   for (int jj = q * 16; jj < q * 16 + 16; ++jj)
     if (i >= jj && i < L)
       ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
@@ -693,6 +715,16 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   // the reflector goes into its diamond
   if (tid < L) vd[(size_t)tid * kG] = vn[tid];
   if (tid == 0) sb[SL.tau2 + dia * kG + cc] = s_tau;
+#ifdef BULGE_STAMPS
+  {
+    BULGE_STAMP(t4)
+    if (tid == 0) {
+      atomicAdd(&g_bulge_stamps[2], t3 - t0);
+      atomicAdd(&g_bulge_stamps[3], t4 - t0);
+      atomicAdd(&g_bulge_stamps[4], 1ull);
+    }
+  }
+#endif
 }
 
 // ================================================================================================================
@@ -1697,6 +1729,19 @@ extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_stamps), sizeof(unsigned long long) * 64 * 8 * 9) == hipSuccess ? 0 : 5;
 #else
   (void)out;
+  return 1;
+#endif
+}
+
+// ---- diagnostic build only: {sum t(E in LDS), sum t(E stored) [tasks with k > 0], sum t(D in LDS), sum t(end), tasks,
+// tasks with k > 0}, cycles since the task's start; reset after the read
+extern "C" int sc_dbg_bulge_stamps(unsigned long long* out6) {
+#ifdef BULGE_STAMPS
+  if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_bulge_stamps), 48) != hipSuccess) return 5;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bulge_stamps), z, 64) == hipSuccess ? 0 : 5;
+#else
+  (void)out6;
   return 1;
 #endif
 }

@@ -14,7 +14,7 @@ for path in sys.argv[1:]:
                 f"{r['kernel']} {r['achieved']} {r['unit']} ({r['frac']})  tri {ph.get('tridiag_ms', 0):.0f} "
                 f"dc {ph.get('tridiag_eigen_ms', 0):.0f} bt {ph.get('backtransform_ms', 0):.0f}")
         if ph.get("two_stage"):
-            print(head + f"  stage1 {ph['band_reduction_ms']:.0f} stage2 {ph['bulge_chasing_ms']:.0f} bt2 {ph['bt2_fused_ms']:.0f} ms "
+            print(head + f"  stage1 {ph['band_reduction_ms']:.0f} stage2 {ph['bulge_chasing_ms']:.0f} bt2 {ph['bt2_apply_ms']:.0f} ms "
                   f"(executed {r.get('executed_tflops')} TF)")
         else:
             print(head + f"  symv {ph.get('symv_ms', 0):.0f} syr2k {ph.get('syr2k_ms', 0):.0f} ms "
