@@ -48,6 +48,8 @@ constexpr int kGemmTile = 3;
 // host cannot look): kGemmAmBk "NN" (sa_i = 1, sb_k = 1), kGemmAkBk "TN" (sa_k = 1, sb_k = 1), kGemmAmBn "NT"
 // (sa_i = 1, sb_j = 1).  Launches that state it (and carry no gather lists) run the MFMA-paced k_gemm2 with a block
 // tile chosen from the launch size; -1 (unknown) runs the older stride-agnostic kernel with the `tile` asked for.
+// lower_grid: every record of the launch is square, lower_only with row_off = col_off = 0 (the SYR2K of the band
+// reduction): only the tiles on and below the diagonal are launched (layout kGemmAmBn, no split-K).
 constexpr int kGemmAmBk = 0, kGemmAkBk = 1, kGemmAmBn = 2;
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k = 1, bool gather = false, bool tri = false, int layout = -1);
+                    int split_k = 1, bool gather = false, bool tri = false, int layout = -1, bool lower_grid = false);

@@ -284,7 +284,7 @@ typedef double __attribute__((address_space(1)))* gptr;             // (a flat a
 // k axis go through the records' index lists, C's columns through c_jidx.  The indices of a K step are loaded one K
 // step before the operands that need them, so the dependent load pair is never waited for.
 template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
-__global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k) {
+__global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k, int lower_grid) {
   static_assert(!GATHER || (AM && !BNC && !TRI), "gather lists: A m-contiguous, B k-contiguous, no triangular mask");
   constexpr int BK = 16;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -297,11 +297,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   double* sA = smem;                       // [2][ImgA::kSize]
   double* sB = smem + 2 * ImgA::kSize;     // [2][ImgB::kSize]
 
-  const int z = blockIdx.z;
+  // lower_grid: the launch only holds the tiles on and below the diagonal (all records lower_only with row_off =
+  // col_off = 0; grid (tiles, records)): row tile b has (BM / BN)(b + 1) column tiles.  A rectangular grid would spend
+  // half of its workgroup dispatches on tiles that return at once, which costs occupancy (1.8 of 3 waves per SIMD).
+  int t_x = blockIdx.x, t_y = blockIdx.y, z = blockIdx.z;
+  if (lower_grid) {
+    constexpr int r = BM / BN;
+    const long long t = blockIdx.x;
+    int b = (int)((sqrt(1.0 + 8.0 * (double)t / r) - 1.0) * 0.5);
+    while ((long long)r * (b + 1) * (b + 2) / 2 <= t) ++b;
+    while ((long long)r * b * (b + 1) / 2 > t) --b;
+    t_x = b; t_y = (int)(t - (long long)r * b * (b + 1) / 2); z = blockIdx.y;
+  }
   const int slice = split_k > 1 ? z % split_k : 0;
   const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
   const int M = D.m, N = D.n, K = D.k;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = t_x * BM, n0 = t_y * BN;
   if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
   if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
 
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
 
 // One instantiation per (block tile, layout, triangular A); its dynamic LDS size is raised above the 64 KB default once.
 template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
-void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k) {
+void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k, bool lower = false) {
   constexpr size_t lds = sizeof(double) * 2 * (size_t)(StageImage<BM, AM>::kSize + StageImage<BN, BNC>::kSize);
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI, GATHER>),
@@ -583,13 +594,18 @@ void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int sp
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k);
+  if (lower) {   // square launch: only the tiles of the lower triangle
+    static_assert(BM % BN == 0, "row tiles are whole multiples of column tiles");
+    const unsigned tiles = (unsigned)((long long)(BM / BN) * grid.x * (grid.x + 1) / 2);
+    grid = dim3(tiles, grid.z, 1);
+  }
+  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k, lower ? 1 : 0);
 }
 
 template <int BM, int BN, bool TRI>
-void launch_gemm2_layout(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k, int layout) {
+void launch_gemm2_layout(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k, int layout, bool lower) {
   if (layout == kGemmAmBn) {
-    if constexpr (!TRI) launch_gemm2_inst<BM, BN, true, true, false>(st, grid, d_desc, split_k);
+    if constexpr (!TRI) launch_gemm2_inst<BM, BN, true, true, false>(st, grid, d_desc, split_k, lower);
   } else if (layout == kGemmAmBk) {
     launch_gemm2_inst<BM, BN, true, false, TRI>(st, grid, d_desc, split_k);
   } else {
@@ -626,7 +642,9 @@ void gemm2_tile(const sc_ctx* ctx, int count, int max_m, int max_n, int split_k,
 }  // namespace
 
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
-                    int split_k, bool gather, bool tri, int layout) {
+                    int split_k, bool gather, bool tri, int layout, bool lower_grid) {
+  static const bool no_lower = getenv("SPRINGCRAFT_GEMM_NO_LOWER_GRID") != nullptr;
+  const bool lower = lower_grid && !no_lower && layout == kGemmAmBn && !tri && !gather && split_k <= 1 && max_m == max_n;
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
   hipStream_t st = ctx->stream;
@@ -651,14 +669,14 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
     if (gz > 65535) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "GEMM launch with %lld records x slices (max 65535)", gz);
     dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)gz);
     if (bm == 128 && bn == 128) {
-      if (tri) launch_gemm2_layout<128, 128, true>(st, grid, d_desc, split_k, layout);
-      else launch_gemm2_layout<128, 128, false>(st, grid, d_desc, split_k, layout);
+      if (tri) launch_gemm2_layout<128, 128, true>(st, grid, d_desc, split_k, layout, lower);
+      else launch_gemm2_layout<128, 128, false>(st, grid, d_desc, split_k, layout, lower);
     } else if (bm == 128) {
-      if (tri) launch_gemm2_layout<128, 64, true>(st, grid, d_desc, split_k, layout);
-      else launch_gemm2_layout<128, 64, false>(st, grid, d_desc, split_k, layout);
+      if (tri) launch_gemm2_layout<128, 64, true>(st, grid, d_desc, split_k, layout, lower);
+      else launch_gemm2_layout<128, 64, false>(st, grid, d_desc, split_k, layout, lower);
     } else {
-      if (tri) launch_gemm2_layout<64, 64, true>(st, grid, d_desc, split_k, layout);
-      else launch_gemm2_layout<64, 64, false>(st, grid, d_desc, split_k, layout);
+      if (tri) launch_gemm2_layout<64, 64, true>(st, grid, d_desc, split_k, layout, lower);
+      else launch_gemm2_layout<64, 64, false>(st, grid, d_desc, split_k, layout, lower);
     }
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -759,7 +777,7 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   // tile 10 .. 13: k_gemm2 (10: automatic block tile, 11: 128 x 128, 12: 128 x 64, 13: 64 x 64); else the old kernel
   const int layout = tile >= 10 ? (mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk)) : -1;
   g_gemm2_force_tile = tile >= 10 ? tile - 10 : 0;
-  SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout));
+  SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, mode == 1 && m == n));
   SC_HIP(ctx, hipStreamSynchronize(st));
   // spot check 64 entries against a host dot product (beta path: C was 0 before the first launch)
   SC_HIP(ctx, hipMemcpy(hc.data(), c, ec * 8, hipMemcpyDeviceToHost));
@@ -782,7 +800,7 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   SC_HIP(ctx, hipEventCreate(&e0));
   SC_HIP(ctx, hipEventCreate(&e1));
   SC_HIP(ctx, hipEventRecord(e0, st));
-  for (int it = 0; it < iters; ++it) SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout));
+  for (int it = 0; it < iters; ++it) SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, mode == 1 && m == n));
   SC_HIP(ctx, hipEventRecord(e1, st));
   SC_HIP(ctx, hipEventSynchronize(e1));
   float ms = 0.f;

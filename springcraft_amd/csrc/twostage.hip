@@ -1608,7 +1608,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     hipLaunchKernelGGL(k_sb_small, dim3((unsigned)batch), dim3(256), lds_small, st, d_tri_ws, TL, d_sb_ws, SL, j0);
     SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
     t_syr2k.start();
-    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile, 1, false, false, kGemmAmBn));
+    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
     t_syr2k.stop();
   }
   SC_HIP(ctx, hipGetLastError());
