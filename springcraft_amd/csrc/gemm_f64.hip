@@ -284,7 +284,8 @@ typedef double __attribute__((address_space(1)))* gptr;             // (a flat a
 // k axis go through the records' index lists, C's columns through c_jidx.  The indices of a K step are loaded one K
 // step before the operands that need them, so the dependent load pair is never waited for.
 template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
-__global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k, int lower_grid) {
+__global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k, int lower_grid,
+                                                  int gx_, int gy_) {
   static_assert(!GATHER || (AM && !BNC && !TRI), "gather lists: A m-contiguous, B k-contiguous, no triangular mask");
   constexpr int BK = 16;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -309,8 +310,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
     while ((long long)r * b * (b + 1) / 2 > t) --b;
     t_x = b; t_y = (int)(t - (long long)r * b * (b + 1) / 2); z = blockIdx.y;
   }
+  // lower_grid == 2 (triangular-operand launches, grid (tiles x * tiles y * records), tiles y, tiles x as kernel
+  // arguments gy_, gx_): the K range of a tile grows (a_tri 1) or shrinks (a_tri 2) with its row, so the tiles are dealt
+  // longest first across all records -- the launch then ends with the shortest tiles instead of with one record's
+  // longest.
+  if (TRI && lower_grid == 2) {
+    const int gz_ = gridDim.x / (gx_ * gy_);
+    z = blockIdx.x % gz_;
+    const int rest = blockIdx.x / gz_;
+    t_y = rest % gy_;
+    t_x = rest / gy_;
+  }
   const int slice = split_k > 1 ? z % split_k : 0;
   const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
+  if (TRI && lower_grid == 2 && D.a_tri == 1) t_x = gx_ - 1 - t_x;
   const int M = D.m, N = D.n, K = D.k;
   const int m0 = t_x * BM, n0 = t_y * BN;
   if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
@@ -599,7 +612,14 @@ void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int sp
     const unsigned tiles = (unsigned)((long long)(BM / BN) * grid.x * (grid.x + 1) / 2);
     grid = dim3(tiles, grid.z, 1);
   }
-  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k, lower ? 1 : 0);
+  int mode = lower ? 1 : 0;
+  const int gx = (int)grid.x, gy = (int)grid.y;
+  static const bool no_balance = getenv("SPRINGCRAFT_GEMM_NO_BALANCE") != nullptr;
+  if (TRI && !lower && !no_balance && (long long)grid.x * grid.y * grid.z < 0x7fffffffLL) {
+    mode = 2;   // longest tiles first, over all records
+    grid = dim3(grid.x * grid.y * grid.z, 1, 1);
+  }
+  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k, mode, gx, gy);
 }
 
 template <int BM, int BN, bool TRI>
