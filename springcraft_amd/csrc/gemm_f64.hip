@@ -285,7 +285,7 @@ typedef double __attribute__((address_space(1)))* gptr;             // (a flat a
 // step before the operands that need them, so the dependent load pair is never waited for.
 template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ descs, int split_k, int lower_grid,
-                                                  int gx_, int gy_) {
+                                                  int gx_, int gy_, int gz_) {
   static_assert(!GATHER || (AM && !BNC && !TRI), "gather lists: A m-contiguous, B k-contiguous, no triangular mask");
   constexpr int BK = 16;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -315,11 +315,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   // longest first across all records -- the launch then ends with the shortest tiles instead of with one record's
   // longest.
   if (TRI && lower_grid == 2) {
-    const int gz_ = gridDim.x / (gx_ * gy_);
     z = blockIdx.x % gz_;
     const int rest = blockIdx.x / gz_;
     t_y = rest % gy_;
     t_x = rest / gy_;
+  }
+  // lower_grid == 3 (few row tiles, e.g. the 256-row products V^T Z of the back-transformation): the gx_ row tiles that
+  // read the same column panel of B run as consecutive workgroups of ONE XCD (workgroups are dealt round-robin to the 8
+  // XCDs), so that panel crosses the fabric once and is served from that XCD's L2 afterwards.
+  if (!TRI && lower_grid == 3) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int group = (slot / gx_) * 8 + xcd;
+    t_x = slot % gx_;
+    t_y = group % gy_;
+    z = group / gy_;
+    if (z >= gz_) return;
   }
   const int slice = split_k > 1 ? z % split_k : 0;
   const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
@@ -613,13 +623,18 @@ void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int sp
     grid = dim3(tiles, grid.z, 1);
   }
   int mode = lower ? 1 : 0;
-  const int gx = (int)grid.x, gy = (int)grid.y;
+  const int gx = (int)grid.x, gy = (int)grid.y, gz = (int)grid.z;
   static const bool no_balance = getenv("SPRINGCRAFT_GEMM_NO_BALANCE") != nullptr;
   if (TRI && !lower && !no_balance && (long long)grid.x * grid.y * grid.z < 0x7fffffffLL) {
     mode = 2;   // longest tiles first, over all records
     grid = dim3(grid.x * grid.y * grid.z, 1, 1);
   }
-  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k, mode, gx, gy);
+  static const bool no_pair = getenv("SPRINGCRAFT_GEMM_NO_PAIR") != nullptr;
+  if (!TRI && !lower && !no_pair && gx >= 2 && gx <= 4 && (long long)(gy * gz + 8) * gx < 0x7fffffffLL) {
+    mode = 3;   // the row tiles of one B panel on one XCD
+    grid = dim3((unsigned)(((long long)gy * gz + 7) / 8 * 8 * gx), 1, 1);
+  }
+  hipLaunchKernelGGL((k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), grid, dim3(256), lds, st, d_desc, split_k, mode, gx, gy, gz);
 }
 
 template <int BM, int BN, bool TRI>
