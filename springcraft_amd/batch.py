@@ -20,7 +20,7 @@ import numpy as np
 from . import _hip
 from .forcefield import device_plan
 
-__all__ = ["DeviceBatchSolver", "shard_bounds", "solve_sharded"]
+__all__ = ["DeviceBatchSolver", "shard_bounds", "solve_sharded", "partition_lpt", "solve_ragged"]
 
 
 def shard_bounds(n_items, world_size, rank):
@@ -180,3 +180,127 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
             return out, v_local
         return w_local[:nloc].cpu().numpy(), v_local
     return w_local[:nloc].cpu().numpy(), v_local
+
+
+def partition_lpt(costs, n_bins):
+    """
+    Longest-processing-time partition (structures of different sizes cost ~ N^3 each): items sorted by cost,
+    largest first (ties: lower index first), each one to the currently least loaded bin (ties: lower bin).  Returns
+    ``n_bins`` index lists, each in ascending item order.  Deterministic, so every rank computes the same partition
+    from the broadcast sizes and no assignment has to be communicated.
+    """
+    costs = [float(c) for c in costs]
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * n_bins
+    bins = [[] for _ in range(n_bins)]
+    for i in order:
+        b = min(range(n_bins), key=lambda r: (load[r], r))
+        bins[b].append(i)
+        load[b] += costs[i]
+    return [sorted(b) for b in bins]
+
+
+def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=None, solvers=None):
+    """
+    Independent structures of DIFFERENT sizes over all ranks of ``group``.
+
+    ``coords_list``: list of (N_i, 3) float64 arrays on the ROOT rank (rank 0); other ranks pass None.  The root
+    broadcasts the sizes, every rank derives the same :func:`partition_lpt` with cost N_i^3, the root scatters one packed
+    (padded) coordinate buffer per rank, each rank solves its structures -- grouped by size, one
+    :class:`DeviceBatchSolver` batch per distinct N -- and the root gathers the packed eigenvalues.  Returns on rank 0
+    the list of eigenvalue arrays in input order, on the other ranks a dict {item index: eigenvalues} of the local items.
+    Two exchange steps, as in :func:`solve_sharded`; eigenvectors are not returned (they stay where they were computed,
+    inside the solvers' buffers).  ``solvers``: optional dict {(n_atoms, batch): DeviceBatchSolver} reused across calls.
+    """
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    backend = dist.get_backend(group) if distributed else None
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" or (
+        not distributed and torch.cuda.is_available() and solver_factory is None) else torch.device("cpu")
+
+    # ---- sizes from the root ---------------------------------------------------------------------------
+    n_items = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        coords_list = [np.ascontiguousarray(c, dtype=np.float64) for c in coords_list]
+        for c in coords_list:
+            if c.ndim != 2 or c.shape[1] != 3:
+                raise ValueError(f"every structure must be an (N, 3) coordinate array, got {c.shape}")
+        n_items[0] = len(coords_list)
+    if distributed:
+        dist.broadcast(n_items, src=0, group=group)
+    B = int(n_items[0])
+    sizes = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
+    if rank == 0 and B:
+        sizes[:B] = torch.tensor([c.shape[0] for c in coords_list], dtype=torch.int64)
+    if distributed:
+        dist.broadcast(sizes, src=0, group=group)
+    sizes = [int(x) for x in sizes[:B].cpu()]
+    parts = partition_lpt([float(n) ** 3 for n in sizes], world)
+    mine = parts[rank]
+    atoms_per_rank = [sum(sizes[i] for i in part) for part in parts]
+    pad_atoms = max(atoms_per_rank + [1])
+
+    # ---- scatter the packed coordinates (one padded buffer per rank) -----------------------------------------
+    local = torch.zeros((pad_atoms, 3), dtype=torch.float64, device=dev)
+    if distributed:
+        chunks = None
+        if rank == 0:
+            chunks = []
+            for part in parts:
+                c = torch.zeros((pad_atoms, 3), dtype=torch.float64, device=dev)
+                off = 0
+                for i in part:
+                    c[off: off + sizes[i]] = torch.from_numpy(coords_list[i]).to(dev)
+                    off += sizes[i]
+                chunks.append(c)
+        dist.scatter(local, chunks, src=0, group=group)
+    else:
+        off = 0
+        for i in mine:
+            local[off: off + sizes[i]] = torch.from_numpy(coords_list[i]).to(dev)
+            off += sizes[i]
+
+    # ---- local solves, one batch per distinct size --------------------------------------------------------------
+    offsets, off = {}, 0
+    for i in mine:
+        offsets[i] = off
+        off += sizes[i]
+    w_local = torch.zeros(pad_atoms * dim, dtype=torch.float64, device=dev)
+    results = {}
+    for n_atoms in sorted({sizes[i] for i in mine}):
+        items = [i for i in mine if sizes[i] == n_atoms]
+        batch = torch.stack([local[offsets[i]: offsets[i] + n_atoms] for i in items]).contiguous()
+        if solver_factory is not None:
+            w_np, _ = solver_factory(n_atoms, len(items))(batch.cpu().numpy())
+            w = torch.from_numpy(np.asarray(w_np))
+        else:
+            key = (n_atoms, len(items))
+            solver = solvers.get(key) if solvers is not None else None
+            if solver is None:
+                solver = DeviceBatchSolver(n_atoms, len(items), force_field, dim=dim, want_vectors=False)
+                if solvers is not None:
+                    solvers[key] = solver
+            w, _ = solver.solve(batch.to(solver.device))
+        for k, i in enumerate(items):
+            w_local[offsets[i] * dim: (offsets[i] + n_atoms) * dim] = w[k].to(dev)
+            results[i] = w[k].cpu().numpy().copy()
+
+    # ---- gather the packed eigenvalues ------------------------------------------------------------------------------
+    if distributed:
+        gathered = [torch.zeros_like(w_local) for _ in range(world)] if rank == 0 else None
+        dist.gather(w_local, gathered, dst=0, group=group)
+        if rank != 0:
+            return results
+        out = [None] * B
+        for r, part in enumerate(parts):
+            off = 0
+            buf = gathered[r].cpu().numpy()
+            for i in part:
+                out[i] = buf[off * dim: (off + sizes[i]) * dim].copy()
+                off += sizes[i]
+        return out
+    return [results[i] for i in range(B)]

@@ -77,6 +77,19 @@ class PhaseTimer {
   std::vector<hipEvent_t> ev_;
 };
 
+// N timing events that are destroyed on every return path (profiling runs only create them).
+template <int N>
+struct ScopedEvents {
+  hipEvent_t e[N];
+  ScopedEvents() { for (auto& x : e) x = nullptr; }
+  ~ScopedEvents() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+  ScopedEvents(const ScopedEvents&) = delete;
+  ScopedEvents& operator=(const ScopedEvents&) = delete;
+  hipEvent_t& operator[](int i) { return e[i]; }
+  hipEvent_t* begin() { return e; }
+  hipEvent_t* end() { return e + N; }
+};
+
 int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);
 
 #define SC_HIP(ctx, call)                                                              \

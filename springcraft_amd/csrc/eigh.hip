@@ -205,7 +205,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
   }
   SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
 
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  ScopedEvents<4> ev;
   float ms_bt2 = 0.f;
   const bool prof = ctx->profiling;
   if (prof) {
@@ -280,7 +280,6 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     ctx->last_timings[5] = 0.0;
     if (P.two) ctx->last_timings[5] = vectors ? ms_bt2 : 1e-9;
     if (t_tf) t_tf->finish();
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads
   return SC_OK;

@@ -532,7 +532,7 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
   const int nb = L.nb;
   // persistent SYMV grid: 4 resident blocks per CU (LDS-limited), shared by the matrices of the batch
   const int symv_blocks = 4 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  ScopedEvents<4> ev;
   const bool prof = ctx->profiling && ms_symv && ms_syr2k;
   if (prof) {
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
@@ -593,6 +593,5 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
   }
   SC_HIP(ctx, hipGetLastError());
   if (prof)
-    for (auto& e : ev) (void)hipEventDestroy(e);
   return SC_OK;
 }

@@ -1485,7 +1485,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                          const TriLayout& TL, double* d_sb_ws, const SbLayout& SL, int* d_dia_off,
                          GemmDesc* d_descs, float* ms_stage1, float* ms_stage2, double* d_band_copy) {
   hipStream_t st = ctx->stream;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  ScopedEvents<3> ev;
   const bool prof = ctx->profiling && ms_stage1 && ms_stage2;
   if (prof) {
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
@@ -1640,7 +1640,6 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_HIP(ctx, hipEventSynchronize(ev[2]));
     SC_HIP(ctx, hipEventElapsedTime(ms_stage1, ev[0], ev[1]));
     SC_HIP(ctx, hipEventElapsedTime(ms_stage2, ev[1], ev[2]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   t_qr.finish(); t_symm.finish(); t_syr2k.finish(); t_bulge.finish();
   SC_HIP(ctx, hipStreamSynchronize(st));   // host descriptor vectors must outlive their uploads
@@ -1669,7 +1668,7 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
                 long long stride_z, int ncols, float* ms_fused) {
   hipStream_t st = ctx->stream;
   if (n < 3 || SL.ndia == 0 || ncols <= 0) return SC_OK;
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  ScopedEvents<2> ev;
   const bool prof = ctx->profiling && ms_fused;
   if (prof) {
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
@@ -1716,7 +1715,6 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     SC_HIP(ctx, hipEventRecord(ev[1], st));
     SC_HIP(ctx, hipEventSynchronize(ev[1]));
     SC_HIP(ctx, hipEventElapsedTime(ms_fused, ev[0], ev[1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return SC_OK;
 }

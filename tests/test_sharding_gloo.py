@@ -66,3 +66,104 @@ def test_solve_sharded_two_ranks(n_items):
     for s in range(n_items):
         h, _ = orc.compute_hessian(orc.synthetic_coord(30, s, 12.0), orc.invariant_ff(8.0))
         assert np.allclose(w[s], orc.eigen(h)[0], atol=1e-10)
+
+
+# ---- ragged batches: longest-processing-time partition by N^3 -------------------------------------------
+def test_partition_lpt_properties():
+    from springcraft_amd.batch import partition_lpt
+
+    sizes = [40, 12, 25, 12, 30, 12, 7, 33]
+    costs = [float(n) ** 3 for n in sizes]
+    for world in (1, 2, 3, 8, 11):
+        parts = partition_lpt(costs, world)
+        assert len(parts) == world
+        assert sorted(i for p in parts for i in p) == list(range(len(sizes)))   # every item exactly once
+        assert parts == partition_lpt(costs, world)                               # deterministic
+        load = [sum(costs[i] for i in p) for p in parts]
+        # Graham's bound for LPT: makespan <= (4/3 - 1/(3m)) OPT, and OPT >= max(largest item, mean load)
+        opt_lb = max(max(costs), sum(costs) / world)
+        assert max(load) <= (4.0 / 3.0 - 1.0 / (3.0 * world)) * opt_lb * (1 + 1e-12) or max(load) == max(costs)
+    # the two largest items never share a bin when there are at least two bins
+    parts = partition_lpt(costs, 2)
+    assert (0 in parts[0]) != (7 in parts[0])
+    assert partition_lpt([], 3) == [[], [], []]
+
+
+_RAGGED = [30, 12, 25, 12, 40, 12, 7]
+
+
+def _ragged_worker(rank, world, port, queue):
+    import torch.distributed as dist
+
+    from oracle import enm_oracle as orc
+    from springcraft_amd.batch import solve_ragged
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def factory(n_atoms, batch):
+        seen.append((n_atoms, batch))
+
+        def run(coords):
+            assert coords.shape == (batch, n_atoms, 3)
+            ws = [orc.eigen(orc.compute_hessian(c, orc.invariant_ff(8.0))[0])[0] for c in coords]
+            return np.array(ws), None
+        return run
+
+    coords = None
+    if rank == 0:
+        coords = [orc.synthetic_coord(n, s, 12.0) for s, n in enumerate(_RAGGED)]
+    out = solve_ragged(coords, None, dim=3, solver_factory=factory)
+    queue.put((rank, out, seen))
+    dist.destroy_process_group()
+
+
+def test_solve_ragged_two_ranks():
+    import torch.multiprocessing as mp
+
+    from oracle import enm_oracle as orc
+    from springcraft_amd.batch import partition_lpt
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, out, seen = q.get(timeout=120)
+        got[r] = (out, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = got[0][0]
+    assert len(w) == len(_RAGGED)
+    for s, n in enumerate(_RAGGED):
+        h, _ = orc.compute_hessian(orc.synthetic_coord(n, s, 12.0), orc.invariant_ff(8.0))
+        assert w[s].shape == (3 * n,)
+        assert np.allclose(w[s], orc.eigen(h)[0], atol=1e-10)
+    # every rank solved exactly its LPT share, one batch per distinct size; the non-root rank returns its items
+    parts = partition_lpt([float(n) ** 3 for n in _RAGGED], 2)
+    for r in range(2):
+        expect = sorted((n, sum(1 for i in parts[r] if _RAGGED[i] == n)) for n in {_RAGGED[i] for i in parts[r]})
+        assert sorted(got[r][1]) == expect
+    assert sorted(got[1][0].keys()) == parts[1]
+
+
+def test_solve_ragged_single_process():
+    from oracle import enm_oracle as orc
+    from springcraft_amd.batch import solve_ragged
+
+    def factory(n_atoms, batch):
+        return lambda coords: (np.array([orc.eigen(orc.compute_hessian(c, orc.invariant_ff(8.0))[0])[0] for c in coords]), None)
+
+    coords = [orc.synthetic_coord(n, s, 12.0) for s, n in enumerate([9, 14, 9])]
+    w = solve_ragged(coords, None, solver_factory=factory)
+    for c, wi in zip(coords, w):
+        assert np.allclose(wi, orc.eigen(orc.compute_hessian(c, orc.invariant_ff(8.0))[0])[0], atol=1e-10)
+    with pytest.raises(ValueError):
+        solve_ragged([np.zeros((4, 2))], None, solver_factory=factory)
+    assert solve_ragged([], None, solver_factory=factory) == []
