@@ -21,6 +21,12 @@ extern "C" {
 int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int split_k, int iters, int beta_one,
                       double* ms_out, double* max_err_out);
 
+/* ONE launch of one GEMM record on host data (a, b laid out as in sc_dbg_gemm_bench for `mode`; c: m x n column-major,
+ * in / out; with split_k > 1 the K slices are summed into c on the host and beta must be 0; lower_grid as the launcher
+ * takes it).  The GPU unit tests of the launch paths compare the result with NumPy.  tests/test_gemm_gpu.py */
+int sc_dbg_gemm_host(sc_ctx* ctx, const double* a, const double* b, double* c, int m, int n, int k, int mode, int tile,
+                     int split_k, double alpha, double beta, int lower_grid);
+
 /* s_memtime segment sums of k_gemm2 (library built with -DGEMM_STAMPS; returns 1 otherwise): out4[0..2] =
  * shader cycles summed over waves in the prologue, the K loop and the C epilogue, out4[3] = waves counted; `reset`
  * zeroes the sums after the read.  tools/gemm_stamps.py */

@@ -846,3 +846,55 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(dd);
   return SC_OK;
 }
+
+// ---- debug entry point for the GPU unit tests of the launch paths (tests/test_gemm_gpu.py): ONE launch of one record
+// on host data.  a, b as sc_dbg_gemm_bench lays them out for `mode`; c: m x n column-major, in / out (with split_k > 1
+// the slices are summed into c on the host and beta must be 0).  lower_grid as launch_gemm_f64 takes it.
+extern "C" int sc_dbg_gemm_host(sc_ctx* ctx, const double* a, const double* b, double* c, int m, int n, int k, int mode,
+                                int tile, int split_k, double alpha, double beta, int lower_grid) {
+  if (!ctx || !a || !b || !c || m <= 0 || n <= 0 || k < 0 || split_k < 1) return SC_ERR_INVALID_ARG;
+  if (split_k > 1 && beta != 0.0) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t ea = (size_t)m * std::max(k, 1), eb = (size_t)std::max(k, 1) * n, ec = (size_t)m * n * split_k;
+  char* base = nullptr;
+  SC_HIP(ctx, hipMalloc((void**)&base, (ea + eb + ec) * 8 + 256));
+  double* da = (double*)base;
+  double* db = da + ea;
+  double* dc = db + eb;
+  GemmDesc* dd = (GemmDesc*)(dc + ec);
+  int rc = SC_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && rc == SC_OK) rc = sc_set_error(ctx, SC_ERR_HIP, "%s", hipGetErrorString(e)); };
+  if (k > 0) { fail(hipMemcpy(da, a, (size_t)m * k * 8, hipMemcpyHostToDevice)); fail(hipMemcpy(db, b, (size_t)k * n * 8, hipMemcpyHostToDevice)); }
+  for (int sl = 0; sl < split_k; ++sl) fail(hipMemcpy(dc + (size_t)sl * m * n, c, (size_t)m * n * 8, hipMemcpyHostToDevice));
+  GemmDesc D{};
+  D.a = da; D.b = db; D.c = dc; D.m = m; D.n = n; D.k = k; D.ldc = m;
+  D.alpha = alpha; D.beta = beta;
+  if (mode == 0) { D.sa_i = 1; D.sa_k = m; D.sb_k = 1; D.sb_j = k; }
+  if (mode == 1) { D.sa_i = 1; D.sa_k = m; D.sb_k = n; D.sb_j = 1; D.lower_only = 1; }
+  if (mode == 2) { D.sa_i = k; D.sa_k = 1; D.sb_k = 1; D.sb_j = k; }
+  D.split_stride = (long long)m * n;
+  fail(hipMemcpy(dd, &D, sizeof(D), hipMemcpyHostToDevice));
+  if (rc == SC_OK) {
+    const int layout = tile >= 10 ? (mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk)) : -1;
+    g_gemm2_force_tile = tile >= 10 ? tile - 10 : 0;
+    rc = launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, lower_grid != 0);
+    g_gemm2_force_tile = 0;
+    fail(hipStreamSynchronize(st));
+  }
+  if (rc == SC_OK) {
+    std::vector<double> h(ec);
+    fail(hipMemcpy(h.data(), dc, ec * 8, hipMemcpyDeviceToHost));
+    if (rc == SC_OK) {
+      if (split_k == 1) std::copy(h.begin(), h.end(), c);
+      else
+        for (size_t i = 0; i < (size_t)m * n; ++i) {
+          double sum = 0.0;
+          for (int sl = 0; sl < split_k; ++sl) sum += h[(size_t)sl * m * n + i];
+          c[i] = sum;
+        }
+    }
+  }
+  (void)hipFree(base);
+  return rc;
+}
