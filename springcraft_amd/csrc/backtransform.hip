@@ -187,7 +187,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       GemmDesc W{};   // W1 = V^T Z[rows], split-K slices
       W.a = vp; W.sa_i = n; W.sa_k = 1;
       W.b = d_z + (size_t)b * stride_z + cs + off; W.sb_k = 1; W.sb_j = n;
-      W.c = bt + BL.w1; W.ldc = nbt;
+      W.c = bt + (w1s > 1 ? BL.w1 : BL.w2); W.ldc = nbt;   // a single K slice goes straight to where the update reads it
       W.m = pc; W.n = ncols; W.k = mrow;
       W.alpha = 1.0; W.beta = 0.0;
       W.split_stride = (long long)nbt * ncols;
@@ -234,7 +234,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
     t_w.start();
     SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s, false, false,
                            kGemmAkBk));
-    hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
+    if (w1s > 1) hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
     t_w.stop();
     t_u.start();
     SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile, 1, false, false,
