@@ -68,6 +68,21 @@ int sc_aux_stream(sc_ctx* ctx) {
   return SC_OK;
 }
 
+int sc_side_streams(sc_ctx* ctx, int count) {
+  while ((int)ctx->side_streams.size() < count) {
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    SC_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(s);
+      return sc_set_error(ctx, SC_ERR_HIP, "hipEventCreateWithFlags failed");
+    }
+    ctx->side_streams.push_back(s);
+    ctx->side_joins.push_back(e);
+  }
+  return SC_OK;
+}
+
 namespace {
 
 int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
@@ -328,6 +343,11 @@ void sc_ctx_destroy(sc_ctx* ctx) {
     (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipEventDestroy(ctx->aux_fork);
     (void)hipEventDestroy(ctx->aux_join);
+  }
+  for (size_t i = 0; i < ctx->side_streams.size(); ++i) {
+    (void)hipStreamSynchronize(ctx->side_streams[i]);
+    (void)hipStreamDestroy(ctx->side_streams[i]);
+    (void)hipEventDestroy(ctx->side_joins[i]);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

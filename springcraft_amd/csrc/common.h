@@ -19,6 +19,9 @@ struct sc_ctx {
   bool own_stream = false;
   // second stream + events for work that is independent of what runs on `stream` (created on first use)
   hipStream_t aux_stream = nullptr;
+  // further side streams (bulge chasing runs parts of the batch side by side) with one join event each
+  std::vector<hipStream_t> side_streams;
+  std::vector<hipEvent_t> side_joins;
   hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   std::string err;
   int num_cus = 0;
@@ -110,6 +113,7 @@ int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...);
 // Grow-only cached allocations.
 int sc_reserve_ws(sc_ctx* ctx, size_t bytes);
 int sc_aux_stream(sc_ctx* ctx);   // creates aux_stream / aux_fork / aux_join if needed
+int sc_side_streams(sc_ctx* ctx, int count);   // makes sure side_streams / side_joins hold `count` entries
 int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
 int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes);
 

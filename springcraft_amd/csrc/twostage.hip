@@ -1627,9 +1627,31 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   if (n >= 3) {
     const int t_max = 2 * (n - 3) + chase_len(n, n - 3) - 1;
     const int gx = chase_len(n, 0) / 2 + 1;
+    // The launches of one chase are strictly ordered and every one of them ends with a partly filled last round of
+    // workgroups.  Parts of the batch on separate streams run the same launches independently of each other, so the
+    // tail of one part's launch is filled by the next launch of another part.
+    static const int env_streams = [] { const char* e = getenv("SPRINGCRAFT_BULGE_STREAMS"); return e ? atoi(e) : 0; }();
+    const int nparts = std::max(1, std::min(env_streams > 0 ? env_streams : (batch >= 16 ? 2 : 1), std::min(batch, 8)));
     t_bulge.start();
-    for (int t = 0; t <= t_max; ++t)
-      hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t);
+    if (nparts > 1) {
+      SC_TRY(sc_aux_stream(ctx));            // (its fork event)
+      SC_TRY(sc_side_streams(ctx, nparts - 1));
+      SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
+      for (int p = 1; p < nparts; ++p) SC_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[p - 1], ctx->aux_fork, 0));
+      for (int t = 0; t <= t_max; ++t)
+        for (int p = 0; p < nparts; ++p) {
+          const int lo = (int)((long long)batch * p / nparts), hi = (int)((long long)batch * (p + 1) / nparts);
+          hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)(hi - lo)), dim3(256), 0,
+                             p == 0 ? st : ctx->side_streams[p - 1], d_sb_ws + (size_t)lo * SL.slab, SL, t);
+        }
+      for (int p = 1; p < nparts; ++p) {
+        SC_HIP(ctx, hipEventRecord(ctx->side_joins[p - 1], ctx->side_streams[p - 1]));
+        SC_HIP(ctx, hipStreamWaitEvent(st, ctx->side_joins[p - 1], 0));
+      }
+    } else {
+      for (int t = 0; t <= t_max; ++t)
+        hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t);
+    }
     t_bulge.stop();
   }
   hipLaunchKernelGGL(k_band_to_tri, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL,
