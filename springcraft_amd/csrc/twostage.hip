@@ -1571,45 +1571,81 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
   static const bool blocked_qr = getenv("SPRINGCRAFT_QR_UNBLOCKED") == nullptr;
   PhaseTimer t_qr(ctx, "panel_qr", st), t_symm(ctx, "symm", st), t_syr2k(ctx, "syr2k", st), t_bulge(ctx, "bulge", st);
-  for (int p = 0; p < npanels; ++p) {
+  // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, SYR2K.
+  auto run_panel = [&](int p, int lo, int hi, hipStream_t ps, bool timed) -> int {
+    struct StreamScope {   // launch_gemm_f64 launches on the context's stream
+      sc_ctx* c; hipStream_t old;
+      StreamScope(sc_ctx* c_, hipStream_t s) : c(c_), old(c_->stream) { c->stream = s; }
+      ~StreamScope() { c->stream = old; }
+    } scope(ctx, ps);
+    const int nb = hi - lo;
+    double* a_h = d_a + (size_t)lo * stride_a;
+    double* tri_h = d_tri_ws + (size_t)lo * TL.slab;
+    double* sb_h = d_sb_ws + (size_t)lo * SL.slab;
     const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
     const int nr = std::min(kB, m - 1);
     const int nchunks = (m + kQrRows - 1) / kQrRows;
-    const dim3 qgrid((unsigned)nchunks, (unsigned)batch);
-    t_qr.start();
+    const dim3 qgrid((unsigned)nchunks, (unsigned)nb);
+    if (timed) t_qr.start();
     if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
-      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, 0,
-                         nr, kIb);
+      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, 0, nr, kIb);
       for (int c0 = 0; c0 < kB; c0 += kIb) {
         for (int j = c0 + 1; j < c0 + kIb; ++j)
-          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
-                             j, nr, c0 + kIb);
+          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, j, nr,
+                             c0 + kIb);
         // (their LDS image holds columns c0 .. kB-1 only)
         const size_t cut = sizeof(double) * (size_t)c0 * (kQrRows + 1);
-        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a - cut, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0,
-                           c0);
+        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, c0);
         if (c0 + kIb < kB)
-          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b - cut, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL,
-                             j0, c0);
+          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, c0);
       }
     } else {
       for (int j = 0; j <= nr; ++j)
-        hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, st, d_a, stride_a, d_tri_ws, TL, d_sb_ws, SL, j0, j, nr,
-                           kB);
+        hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, j, nr, kB);
     }
-    t_qr.stop();
-    const GemmDesc* g = d_descs + (size_t)p * 6 * batch;
-    t_symm.start();
-    SC_TRY(launch_gemm_f64(ctx, g, batch, m, kB, kGemmTile, 1, false, true, kGemmAmBk));           // X1 = L V
-    SC_TRY(launch_gemm_f64(ctx, g + batch, batch, m, kB, kGemmTile, 1, false, true, kGemmAkBk));   // X2 = strict(L)^T V
-    t_symm.stop();
-    SC_TRY(launch_gemm_f64(ctx, g + 2 * batch, batch, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
-    hipLaunchKernelGGL(k_sb_small, dim3((unsigned)batch), dim3(256), lds_small, st, d_tri_ws, TL, d_sb_ws, SL, j0);
-    SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
-    t_syr2k.start();
-    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch, batch, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
-    t_syr2k.stop();
+    if (timed) t_qr.stop();
+    const GemmDesc* g = d_descs + (size_t)p * 6 * batch;   // [kind][batch]
+    if (timed) t_symm.start();
+    SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, 1, false, true, kGemmAmBk));           // X1 = L V
+    SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, 1, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+    if (timed) t_symm.stop();
+    SC_TRY(launch_gemm_f64(ctx, g + 2 * batch + lo, nb, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
+    hipLaunchKernelGGL(k_sb_small, dim3((unsigned)nb), dim3(256), lds_small, ps, tri_h, TL, sb_h, SL, j0);
+    if (nb == batch) {
+      SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+    } else {
+      SC_TRY(launch_gemm_f64(ctx, g + 3 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+      SC_TRY(launch_gemm_f64(ctx, g + 4 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+    }
+    if (timed) t_syr2k.start();
+    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
+    if (timed) t_syr2k.stop();
+    return SC_OK;
+  };
+  // Two parts of a large batch on separate streams: the latency-bound panel QR of one part runs beside the GEMMs of the
+  // other (618 -> 591 ms per step at 64 matrices).  A profiled solve keeps everything on one stream, because the
+  // kernel-group times (panel_qr / symm / syr2k) are event brackets on that stream: its band reduction is therefore
+  // about 30 ms longer than in an unprofiled solve.
+  static const int env_s1 = [] { const char* e = getenv("SPRINGCRAFT_STAGE1_STREAMS"); return e ? atoi(e) : 0; }();
+  const int s1_want = env_s1 > 0 ? env_s1 : ((batch >= 32 && !prof) ? 2 : 1);
+  const int s1_parts = std::max(1, std::min(s1_want, std::min(batch, 4)));
+  if (s1_parts > 1) {
+    SC_TRY(sc_aux_stream(ctx));
+    SC_TRY(sc_side_streams(ctx, s1_parts - 1));
+    SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
+    for (int q = 1; q < s1_parts; ++q) SC_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[q - 1], ctx->aux_fork, 0));
+    for (int p = 0; p < npanels; ++p)
+      for (int q = 0; q < s1_parts; ++q) {
+        const int lo = (int)((long long)batch * q / s1_parts), hi = (int)((long long)batch * (q + 1) / s1_parts);
+        SC_TRY(run_panel(p, lo, hi, q == 0 ? st : ctx->side_streams[q - 1], q == 0));
+      }
+    for (int q = 1; q < s1_parts; ++q) {
+      SC_HIP(ctx, hipEventRecord(ctx->side_joins[q - 1], ctx->side_streams[q - 1]));
+      SC_HIP(ctx, hipStreamWaitEvent(st, ctx->side_joins[q - 1], 0));
+    }
+  } else {
+    for (int p = 0; p < npanels; ++p) SC_TRY(run_panel(p, 0, batch, st, true));
   }
   SC_HIP(ctx, hipGetLastError());
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
