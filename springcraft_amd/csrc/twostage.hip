@@ -609,9 +609,10 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
     const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kG + cc;
     const double tau_p = sb[SL.tau2 + (dia - 1) * kG + cc];
     if (tid < kB) vp[tid] = vdp[(size_t)tid * kG];
-    // E(i, j) = AB(r0 + i, c0 + j), rows i < L
+    // E(i, j) = AB(r0 + i, c0 + j), rows i < L: thread (i, q) keeps row i, columns 16 q .. 16 q + 15 in registers for the
+    // row-wise steps; only the column sums of the second reflector go through an LDS image.
+    double t16[16];
     {
-      double t16[16];
       const int ic = std::min(i, L - 1);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -619,32 +620,35 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
         t16[u] = ab[(size_t)(kB + ic - jj) + (size_t)(c0 + jj) * kLdab];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) E[i * LD + q * 16 + u] = i < L ? t16[u] : 0.0;
+      for (int u = 0; u < 16; ++u) t16[u] = i < L ? t16[u] : 0.0;
     }
-    lds_barrier();
+    lds_barrier();   // vp
 #ifdef BULGE_STAMPS
     { BULGE_STAMP(t1) if (tid == 0) atomicAdd(&g_bulge_stamps[0], t1 - t0); }
 #endif
-    // u = E vp
+    // u = tau_p E vp: partial sums over this wave's 16 columns, every thread adds the four partials of its own row
     {
       double a = 0.0;
 #pragma unroll
-      for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += E[i * LD + jj] * vp[jj];
+      for (int u = 0; u < 16; ++u) a += t16[u] * vp[q * 16 + u];
       red[q * kB + i] = a;
     }
     lds_barrier();
-    if (tid < kB) u[tid] = tau_p * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
-    lds_barrier();
+    {
+      const double ui = tau_p * ((red[i] + red[kB + i]) + (red[2 * kB + i] + red[3 * kB + i]));
 #pragma unroll
-    for (int jj = q * 16; jj < q * 16 + 16; ++jj) E[i * LD + jj] -= u[i] * vp[jj];
-    lds_barrier();
-    // new reflector from the first column of E
-    if (tid < 64) {
-      const double x = E[tid * LD];
-      const double t2 = wave_sum((tid >= 1 && tid < L) ? x * x : 0.0);
-      const HH h = householder(E[0], t2);
-      vn[tid] = tid == 0 ? 1.0 : (tid < L ? x * h.scale : 0.0);
-      if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
+      for (int u = 0; u < 16; ++u) {
+        t16[u] -= ui * vp[q * 16 + u];
+        E[i * LD + q * 16 + u] = t16[u];
+      }
+    }
+    // new reflector from the first column of E, which wave 0 holds in t16[0]
+    if (q == 0) {
+      const double x = t16[0];
+      const double t2 = wave_sum((i >= 1 && i < L) ? x * x : 0.0);
+      const HH h = householder(__shfl(x, 0), t2);
+      vn[i] = i == 0 ? 1.0 : (i < L ? x * h.scale : 0.0);
+      if (i == 0) { s_tau = h.tau; s_beta = h.beta; }
     }
     lds_barrier();
     // z_j = sum_i E[i, j] v_i  (j >= 1);  thread (j = i, rows q*16..)
@@ -657,13 +661,15 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
     lds_barrier();
     if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
     lds_barrier();
-    // E <- H E, first column = beta e1; write back
-    for (int jj = q * 16; jj < q * 16 + 16; ++jj) {
-      double e = E[i * LD + jj] - vn[i] * u[jj];
+    // E <- H E (from the registers), first column = beta e1; write back.  Nobody reads the LDS image of E any more (the
+    // column sums were two barriers ago), so the diagonal block may take over its buffer without another barrier.
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int jj = q * 16 + c;
+      double e = t16[c] - vn[i] * u[jj];
       if (jj == 0) e = i == 0 ? s_beta : 0.0;
       if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
     }
-    lds_barrier();   // D reuses E's buffer
 #ifdef BULGE_STAMPS
     { BULGE_STAMP(t2) if (tid == 0) { atomicAdd(&g_bulge_stamps[1], t2 - t0); atomicAdd(&g_bulge_stamps[5], 1ull); } }
 #endif
