@@ -27,7 +27,8 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus
                 Durations from HIP events on the solver's stream in one extra profiled step right after the timed
                 region.  ``traffic`` only from a PMC pass collected at the benchmarked (n, batch), else null.
   rooflines     the other two rooflines BASELINE.json's north star names: ``assembly`` (k_hessian: 72 B per ordered
-                atom pair / kernel time vs 8 TB/s HBM) and ``band_reduction`` / ``syr2k`` (f64-MFMA fraction)
+                atom pair / kernel time vs 8 TB/s HBM) and ``band_reduction`` / ``syr2k`` (f64-MFMA fraction), plus
+                ``bulge_chasing`` (k_bulge_step: algorithmic bytes of the chase / wall time of the stage vs 8 TB/s)
   parity_gates  SURVEY.md section 8(d): contact counts, pair list, Kirchhoff (bit exact), Hessian (rel. Frobenius),
                 eigenvalues vs the CPU run, residual and orthogonality of several structures of the timed batch
   cpu_baseline  the oracle (NumPy restatement of compute_hessian + numpy.linalg.eigh = LAPACK dsyevd, the
@@ -71,6 +72,21 @@ def bt2_flops(n, ncols):
     ngroups = (n - 2 + 63) // 64
     ndia = sum((n - 1 - 64 * g + 63) // 64 for g in range(ngroups))
     return 4.0 * total_len * ncols, 2.0 * 64 * (80 + 64 + 40) * ndia * ncols
+
+
+def bulge_bytes(n):
+    """
+    Algorithmic bytes of the bulge chase per matrix (k_bulge_step): task (sweep s, position k) owns the rows r0 .. r0+L-1,
+    r0 = s + 1 + 64 k, L = min(64, n - r0); it reads and writes the L x 64 off-diagonal block (k > 0) and the lower
+    triangle of the L x L diagonal block.
+    """
+    s = np.arange(0, n - 2, dtype=np.int64)
+    total = 0
+    for k in range((n - 1 + 63) // 64):
+        r0 = s + 1 + 64 * k
+        L = np.clip(n - r0, 0, 64)
+        total += int((2 * 8 * (L * (L + 1) // 2 + (64 * L if k > 0 else 0))).sum())
+    return total
 
 
 def pmc_traffic(kind, n, batch):
@@ -258,6 +274,17 @@ def run_c3(args, rank, world, torch, dist):
                     "bound": "mfma", "achieved": round(sy, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(sy / F64_MFMA_PEAK_TF, 4),
                     "what": "trailing SYR2K launches of the band reduction alone: 2/3 n^3 flops per matrix / their duration",
+                }
+            if t.get("bulge_chasing_ms", 0) > 0:
+                bb = bulge_bytes(n) * B
+                bw = bb / (t["bulge_chasing_ms"] * 1e-3) / 1e9
+                rooflines["bulge_chasing"] = {
+                    "kernel": "k_bulge_step", "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(bw / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": bb,
+                    "what": "stage 2 (band -> tridiagonal): every task reads and writes its off-diagonal block and the lower "
+                            "triangle of its diagonal block / wall time of the stage (HIP events; its launches run as two "
+                            "halves of the batch on two streams, so per-kernel durations in a rocprof summary overlap and "
+                            "add up to more than this)",
                 }
         else:
             launches = (n - 2)
