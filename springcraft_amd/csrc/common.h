@@ -38,6 +38,7 @@ struct sc_ctx {
   size_t dc_aux_bytes = 0;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
+  int chase_ok = -1;    // persistent bulge chase usable on this device: -1 not probed yet, 0 no, 1 yes (twostage.hip)
   bool profiling = false;
   double last_timings[6] = {0, 0, 0, 0, 0, 0};
   // named kernel-group durations of the most recent profiled eigensolve (sc_last_eigh_phase_ms)

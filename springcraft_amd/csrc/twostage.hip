@@ -733,6 +733,215 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 #endif
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Persistent form of the bulge chase: ONE launch, no launch per wavefront.  Workgroup (matrix b, lane r of W) takes the
+// sweeps s = r, r + W, ... of its matrix and walks each of them down the band, task after task; task (s, k) starts when
+// sweep s - 1 has published k + 2 finished tasks (progress[b][s - 1], one counter per sweep), which is the only
+// dependence the chase has.  The previous reflector of the sweep stays in LDS (no round trip through the diamond
+// storage), a sweep never waits for a launch boundary, and the matrices drift apart freely, so no round of workgroups is
+// left half empty.
+//
+// Coherence without L2 write-backs: all W workgroups of a matrix sit on ONE XCD (matrix b on XCD b mod 8; a workgroup
+// reads the XCD it runs on from XCC_ID and draws its role there), i.e. behind one L2.  A task's stores are drained (vmcnt(0)) and fenced by a workgroup barrier before thread 0
+// publishes the counter; consumers read the counter and the band through agent-scope relaxed atomic loads, which bypass
+// the CU's L1 and are served by that L2 (26 us per hand-off with release / acquire at agent scope, 3 us this way:
+// tools/probe_handoff.hip).  The launch is cooperative (all workgroups resident); every spin is bounded and a time-out
+// raises a flag that ends all workgroups, so the kernel terminates whatever happens (the host then reports an error).
+__device__ __forceinline__ double ld_l2(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
+                                                     int* __restrict__ progress, int* __restrict__ flags) {
+  constexpr int LD = kB + 1;
+  __shared__ double E[kB * LD];
+  double* D = E;
+  __shared__ double vbuf[2][kB], u[kB], red[4 * kB];
+  __shared__ double s_tau, s_beta;
+  __shared__ int s_go;
+
+  const int n = SL.n;
+  const int tid = threadIdx.x;
+  const int i = tid & 63, q = tid >> 6;
+  // Role from the XCD the workgroup really runs on (XCC_ID) and a ticket drawn there: the launch fills the chip
+  // (gridDim.x = resident workgroups per CU x CUs), so every XCD hands out the same gridDim.x / 8 tickets and all W
+  // roles of each of its `groups` matrices in flight are taken.  flags[2 + xcd] are the ticket counters.
+  __shared__ int s_xcd, s_slot;
+  if (tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    s_xcd = (int)(id & 7u);
+    s_slot = atomicAdd(flags + 2 + s_xcd, 1);
+  }
+  __syncthreads();
+  const int xcd = s_xcd, slot = s_slot;
+  const int groups = (gridDim.x >> 3) / W;          // matrices in flight per XCD
+  const int grp = slot / W, r = slot % W;
+  if (grp >= groups) return;
+  const int K0 = chase_len(n, 0);
+
+  for (int b = xcd + 8 * grp; b < batch; b += 8 * groups) {
+    double* sb = sb_all + (size_t)b * SL.slab;
+    double* ab = sb + SL.ab;
+    int* prog = progress + (size_t)b * n;
+    for (int s = r; s <= n - 3; s += W) {
+      const int len = chase_len(n, s);
+      const int S = s / kG, cc = s - S * kG;
+      const size_t dia0 = (size_t)S * K0 - (size_t)S * (S - 1) / 2;
+      const int len_prev = s > 0 ? chase_len(n, s - 1) : 0;
+      double tau_p = 0.0;
+      for (int k = 0; k < len; ++k) {
+        double* vp = vbuf[(k + 1) & 1];   // reflector of task k - 1 of this sweep
+        double* vn = vbuf[k & 1];
+        // ---- wait for sweep s - 1
+        if (tid == 0) {
+          int go = 1;
+          if (s > 0) {
+            const int need = min(k + 2, len_prev);
+            long spins = 0;
+            while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+              if (++spins > (1L << 21) || __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                go = 0;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) return;
+
+        const int r0 = s + 1 + k * kB;
+        const int L = min(kB, n - r0);
+        const size_t dia = dia0 + k;
+        double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kG + cc;
+        double d16[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int jc = min(q * 16 + c, L - 1);
+          const int ic = min(max(i, jc), L - 1);
+          d16[c] = ld_l2(ab + (size_t)(ic - jc) + (size_t)(r0 + jc) * kLdab);
+        }
+        if (k > 0) {
+          const int c0 = r0 - kB;
+          double t16[16];
+          {
+            const int ic = min(i, L - 1);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              const int jj = q * 16 + c;
+              t16[c] = ld_l2(ab + (size_t)(kB + ic - jj) + (size_t)(c0 + jj) * kLdab);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t16[c] = i < L ? t16[c] : 0.0;
+          }
+          {
+            double a = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a += t16[c] * vp[q * 16 + c];
+            red[q * kB + i] = a;
+          }
+          lds_barrier();
+          {
+            const double ui = tau_p * ((red[i] + red[kB + i]) + (red[2 * kB + i] + red[3 * kB + i]));
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              t16[c] -= ui * vp[q * 16 + c];
+              E[i * LD + q * 16 + c] = t16[c];
+            }
+          }
+          if (q == 0) {
+            const double x = t16[0];
+            const double t2 = wave_sum((i >= 1 && i < L) ? x * x : 0.0);
+            const HH h = householder(__shfl(x, 0), t2);
+            vn[i] = i == 0 ? 1.0 : (i < L ? x * h.scale : 0.0);
+            if (i == 0) { s_tau = h.tau; s_beta = h.beta; }
+          }
+          lds_barrier();
+          {
+            double a = 0.0;
+#pragma unroll
+            for (int ii = q * 16; ii < q * 16 + 16; ++ii) a += E[ii * LD + i] * vn[ii];
+            red[q * kB + i] = a;
+          }
+          lds_barrier();
+          if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
+          lds_barrier();
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const int jj = q * 16 + c;
+            double e = t16[c] - vn[i] * u[jj];
+            if (jj == 0) e = i == 0 ? s_beta : 0.0;
+            if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
+          }
+        } else {
+          if (tid < 64) {
+            const double xr = ld_l2(ab + (size_t)(1 + min(tid, L - 1)) + (size_t)s * kLdab);
+            const double x = tid < L ? xr : 0.0;
+            const double t2 = wave_sum(tid >= 1 ? x * x : 0.0);
+            const HH h = householder(__shfl(x, 0), t2);
+            vn[tid] = tid == 0 ? 1.0 : x * h.scale;
+            if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
+            if (tid < L) ab[(size_t)(1 + tid) + (size_t)s * kLdab] = tid == 0 ? h.beta : 0.0;
+          }
+          lds_barrier();
+        }
+        // ---- diagonal block
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int jj = q * 16 + c;
+          if (i >= jj) {
+            const double x = (i < L) ? d16[c] : 0.0;
+            D[i * LD + jj] = x;
+            D[jj * LD + i] = x;
+          }
+        }
+        lds_barrier();
+        {
+          double a = 0.0;
+#pragma unroll
+          for (int jj = q * 16; jj < q * 16 + 16; ++jj) a += D[i * LD + jj] * vn[jj];
+          red[q * kB + i] = a;
+        }
+        lds_barrier();
+        const double tau_now = s_tau;
+        if (tid < 64) {
+          const double pp = tau_now * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
+          const double dot = wave_sum(pp * vn[tid]);
+          u[tid] = pp - 0.5 * tau_now * dot * vn[tid];
+        }
+        lds_barrier();
+        for (int jj = q * 16; jj < q * 16 + 16; ++jj)
+          if (i >= jj && i < L)
+            ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
+        if (tid < L) vd[(size_t)tid * kG] = vn[tid];
+        if (tid == 0) sb[SL.tau2 + dia * kG + cc] = tau_now;
+        tau_p = tau_now;
+        // ---- publish: this task's stores are in the L2 before the counter moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(prog + s, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// Census with the footprint of k_bulge_chase (same block size, same LDS): how many workgroups of a chip-filling launch
+// land on each XCD.  The chase draws its roles per XCD and needs every XCD to receive exactly its share.
+__global__ __launch_bounds__(256) void k_chase_census(int* __restrict__ counts) {
+  __shared__ double pad[kB * (kB + 1) + 2 * kB + kB + 4 * kB + 4];
+  if (threadIdx.x == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    atomicAdd(counts + (id & 7u), 1);
+    pad[0] = 0.0;
+  }
+  __syncthreads();
+  if (pad[threadIdx.x & 1] != 0.0) counts[8] = 1;   // (keeps the LDS allocation)
+}
+
 // ================================================================================================================
 // Diamonds: T factor and V T.  One workgroup per (diamond, matrix).  The diamond is held compactly in LDS
 // (Vc[c][i] = V[c + i, c], the 64 entries of reflector c), G and T share one buffer (G is only read by the first
@@ -1672,10 +1881,69 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // The launches of one chase are strictly ordered and every one of them ends with a partly filled last round of
     // workgroups.  Parts of the batch on separate streams run the same launches independently of each other, so the
     // tail of one part's launch is filled by the next launch of another part.
+    // ---- persistent chase (one cooperative launch) when the device places workgroups as the kernel's coherence scheme
+    // assumes and all its workgroups fit; else, or with SPRINGCRAFT_BULGE_PERSISTENT=0, one launch per wavefront below
+    static const int env_persist = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PERSISTENT"); return e ? atoi(e) : 1; }();
+    bool chased = false;
+    // it pays while the stage is latency-bound (a wavefront's tasks fit the chip about once): measured crossover
+    // batch * n / 128 ~ 1200 (tools/bulge_sweep.py); beyond that the per-wavefront launches on two streams are faster
+    const bool want_chase = env_persist == 2 || (env_persist == 1 && (long long)batch * n / 128 <= 1200);
+    if (want_chase && ctx->num_cus > 0 && ctx->num_cus % 8 == 0 && ctx->chase_ok != 0) {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
+      if (ctx->chase_ok < 0 && per_cu > 0) {   // once per context: does a chip-filling launch give every XCD its share?
+        SC_TRY(sc_reserve_dc_aux(ctx, 256));
+        int* d_counts = reinterpret_cast<int*>(ctx->dc_aux);
+        SC_HIP(ctx, hipMemsetAsync(d_counts, 0, 64, st));
+        void* cargs[] = {&d_counts};
+        int h_counts[9] = {0};
+        bool ok = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_chase_census),
+                                             dim3((unsigned)(per_cu * ctx->num_cus)), dim3(256), cargs, 0, st) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        SC_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, st));
+        SC_HIP(ctx, hipStreamSynchronize(st));
+        for (int x = 0; x < 8; ++x) ok = ok && h_counts[x] == per_cu * ctx->num_cus / 8;
+        ctx->chase_ok = ok ? 1 : 0;
+      }
+      if (ctx->chase_ok != 1) per_cu = 0;
+      const int slots_per_xcd = per_cu * ctx->num_cus / 8;
+      const int mpx = (batch + 7) / 8;   // matrices per XCD
+      const int W = slots_per_xcd > 0 ? std::min(32, std::max(8, slots_per_xcd / mpx)) : 0;
+      const int groups = W > 0 ? std::min(mpx, slots_per_xcd / W) : 0;
+      if (groups >= 1) {
+        const size_t prog_bytes = align_up((size_t)batch * n * sizeof(int), 256);
+        SC_TRY(sc_reserve_dc_aux(ctx, prog_bytes + 256));
+        int* d_prog = reinterpret_cast<int*>(ctx->dc_aux);
+        int* d_flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes);
+        SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + 256, st));
+        double* a_sb = d_sb_ws;
+        SbLayout a_sl = SL;
+        int a_batch = batch, a_w = W;
+        void* args[] = {&a_sb, &a_sl, &a_batch, &a_w, &d_prog, &d_flags};
+        t_bulge.start();
+        // the whole chip, so that every XCD gets its share of workgroups (roles are drawn per XCD inside the kernel)
+        const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_bulge_chase),
+                                                         dim3((unsigned)(per_cu * ctx->num_cus)), dim3(256), args, 0, st);
+        if (le == hipSuccess) {
+          t_bulge.stop();
+          int h_flags[2] = {0, 0};
+          SC_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+          SC_HIP(ctx, hipStreamSynchronize(st));
+          if (h_flags[0])
+            return sc_set_error(ctx, SC_ERR_HIP, "persistent bulge chase: a progress wait timed out; set "
+                                "SPRINGCRAFT_BULGE_PERSISTENT=0");
+          chased = true;
+        } else {
+          t_bulge.stop();
+          (void)hipGetLastError();   // not launchable here (grid does not fit): the stepwise path takes over
+        }
+      }
+    }
     static const int env_streams = [] { const char* e = getenv("SPRINGCRAFT_BULGE_STREAMS"); return e ? atoi(e) : 0; }();
     const int nparts = std::max(1, std::min(env_streams > 0 ? env_streams : (batch >= 16 ? 2 : 1), std::min(batch, 8)));
-    t_bulge.start();
-    if (nparts > 1) {
+    if (!chased) t_bulge.start();
+    if (chased) {
+    } else if (nparts > 1) {
       SC_TRY(sc_aux_stream(ctx));            // (its fork event)
       SC_TRY(sc_side_streams(ctx, nparts - 1));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
@@ -1694,7 +1962,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       for (int t = 0; t <= t_max; ++t)
         hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t);
     }
-    t_bulge.stop();
+    if (!chased) t_bulge.stop();
   }
   hipLaunchKernelGGL(k_band_to_tri, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL,
                      d_tri_ws, TL);
