@@ -569,7 +569,7 @@ __device__ unsigned long long g_bulge_stamps[8];
 
 // Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
 __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
-                                                    int t) {
+                                                    int t, const int* __restrict__ done = nullptr) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
   double* D = E;   // the diagonal block is processed after E has gone back to memory: same buffer
@@ -580,6 +580,8 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   const int k = (t & 1) + 2 * (int)blockIdx.x;
   const int s = (t - k) / 2;
   if (s < 0 || s > n - 3 || k >= chase_len(n, s)) return;
+  // resuming a persistent chase that gave up (k_bulge_chase): done[b][s] tasks of sweep s are finished already
+  if (done && k < done[(size_t)blockIdx.y * n + s]) return;
   double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
   double* ab = sb + SL.ab;
   const int S = s / kG, cc = s - S * kG;
@@ -752,7 +754,8 @@ __device__ __forceinline__ double ld_l2(const double* p) {
 }
 
 __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
-                                                     int* __restrict__ progress, int* __restrict__ flags) {
+                                                     int* __restrict__ progress, int* __restrict__ flags,
+                                                     int give_up_after) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
   double* D = E;
@@ -795,8 +798,8 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         double* vn = vbuf[k & 1];
         // ---- wait for sweep s - 1
         if (tid == 0) {
-          int go = 1;
-          if (s > 0) {
+          int go = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
+          if (go && s > 0) {
             const int need = min(k + 2, len_prev);
             long spins = 0;
             while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
@@ -922,7 +925,12 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         // ---- publish: this task's stores are in the L2 before the counter moves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(prog + s, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+          __hip_atomic_store(prog + s, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // test hook (SPRINGCRAFT_BULGE_GIVE_UP): raise the time-out flag after that many tasks of this workgroup
+          if (give_up_after > 0 && --give_up_after == 0)
+            __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -1918,8 +1926,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
         SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + 256, st));
         double* a_sb = d_sb_ws;
         SbLayout a_sl = SL;
-        int a_batch = batch, a_w = W;
-        void* args[] = {&a_sb, &a_sl, &a_batch, &a_w, &d_prog, &d_flags};
+        static const int env_give_up = [] { const char* e = getenv("SPRINGCRAFT_BULGE_GIVE_UP"); return e ? atoi(e) : 0; }();
+        int a_batch = batch, a_w = W, a_give_up = env_give_up;
+        void* args[] = {&a_sb, &a_sl, &a_batch, &a_w, &d_prog, &d_flags, &a_give_up};
         t_bulge.start();
         // the whole chip, so that every XCD gets its share of workgroups (roles are drawn per XCD inside the kernel)
         const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_bulge_chase),
@@ -1929,9 +1938,17 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
           int h_flags[2] = {0, 0};
           SC_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
           SC_HIP(ctx, hipStreamSynchronize(st));
-          if (h_flags[0])
-            return sc_set_error(ctx, SC_ERR_HIP, "persistent bulge chase: a progress wait timed out; set "
-                                "SPRINGCRAFT_BULGE_PERSISTENT=0");
+          if (h_flags[0]) {
+            // A wait ran into its bound (e.g. another process holds part of the GPU, so not all workgroups were
+            // resident).  Workgroups only stop between tasks and every finished task is published, so the counters
+            // describe a consistent state: the per-wavefront launches finish the chase, skipping what is done.
+            ctx->chase_ok = 0;
+            const int t_max2 = 2 * (n - 3) + chase_len(n, n - 3) - 1;
+            for (int t = 0; t <= t_max2; ++t)
+              hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)(chase_len(n, 0) / 2 + 1), (unsigned)batch), dim3(256), 0, st,
+                                 d_sb_ws, SL, t, (const int*)d_prog);
+            SC_HIP(ctx, hipGetLastError());
+          }
           chased = true;
         } else {
           t_bulge.stop();

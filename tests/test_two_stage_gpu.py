@@ -193,3 +193,38 @@ def test_batched_ragged_order(sc):
             assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
             check_eigenvectors(mats[b], w, v, tol_res=1e-11, tol_orth=1e-11)
     ctx.close()
+
+
+@pytest.mark.parametrize("give_up", [0, 5, 300])
+def test_persistent_chase_and_resume(give_up):
+    """
+    The persistent bulge chase (forced), alone and giving up after `give_up` tasks per workgroup: the per-wavefront
+    launches then finish the chase from the published progress counters.  Own process: the library reads the switches once.
+    """
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np
+import springcraft_amd as sc
+from springcraft_amd import _hip
+rs = np.random.RandomState(7)
+for n, batch in ((1030, 1), (520, 3)):
+    mats = []
+    for b in range(batch):
+        a = rs.standard_normal((n, n)); mats.append(0.5 * (a + a.T))
+    ctx = _hip.context()
+    ctx.set_two_stage(True)
+    for a in mats:
+        w, v = sc.nma.eigh(a)
+        w_ref = np.linalg.eigvalsh(a)
+        assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max(), np.abs(w - w_ref).max()
+        assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-10 * np.abs(w_ref).max()
+        assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-11
+print("ok")
+'''
+    env = dict(os.environ, SPRINGCRAFT_BULGE_PERSISTENT="2", SPRINGCRAFT_BULGE_GIVE_UP=str(give_up))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
