@@ -1895,7 +1895,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     bool chased = false;
     // it pays while the stage is latency-bound (a wavefront's tasks fit the chip about once): measured crossover
     // batch * n / 128 ~ 1200 (tools/bulge_sweep.py); beyond that the per-wavefront launches on two streams are faster
-    const bool want_chase = env_persist == 2 || (env_persist == 1 && (long long)batch * n / 128 <= 1200);
+    // and, with fewer matrices than XCDs (a matrix is confined to one XCD), only while the order is moderate: a single
+    // n = 12000 matrix chases 1.5 x faster with its ~94 tasks per wavefront spread over the whole chip
+    const bool want_chase = env_persist == 2 ||
+                            (env_persist == 1 && (long long)batch * n / 128 <= 1200 && (batch >= 8 || n <= 6144));
     if (want_chase && ctx->num_cus > 0 && ctx->num_cus % 8 == 0 && ctx->chase_ok != 0) {
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
@@ -1916,7 +1919,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       if (ctx->chase_ok != 1) per_cu = 0;
       const int slots_per_xcd = per_cu * ctx->num_cus / 8;
       const int mpx = (batch + 7) / 8;   // matrices per XCD
-      const int W = slots_per_xcd > 0 ? std::min(32, std::max(8, slots_per_xcd / mpx)) : 0;
+      // workgroups per matrix: all the XCD's slots divided by its matrices, but no more than sweeps can be in flight
+      // (every sweep trails its predecessor by two tasks)
+      const int useful = std::max(8, chase_len(n, 0) / 2 + 1);
+      const int W = slots_per_xcd > 0 ? std::max(1, std::min(useful, slots_per_xcd / mpx)) : 0;
       const int groups = W > 0 ? std::min(mpx, slots_per_xcd / W) : 0;
       if (groups >= 1) {
         const size_t prog_bytes = align_up((size_t)batch * n * sizeof(int), 256);
