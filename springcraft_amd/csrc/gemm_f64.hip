@@ -716,8 +716,9 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
   }
-  // gather / tri launches always run the 64 x 64 x 8 instantiation: size the grid and the LDS for that tile
-  if (gather || tri) tile = 3;
+  // gather / tri launches always run the 64 x 64 x 8 instantiation: size the grid and the LDS for that tile; so does any
+  // tile id this kernel does not have (the k_gemm2 ids 10 .. 13 of the debug entry points when k_gemm2 is switched off)
+  if (gather || tri || tile < 0 || tile > 3) tile = 3;
   const int bm = tile == 0 ? 128 : 64;
   const int bn = (tile == 2 || tile == 3) ? 64 : 128;
   const int bk = tile == 3 ? 8 : 16;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# The eigensolver tests under every switch that selects an alternative code path (on the GPU box):  bash tools/test_matrix.sh
+set -u
+T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py"
+run() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q 2>&1 | tail -1; }
+run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=1 SPRINGCRAFT_STAGE1_STREAMS=1
+run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3
+run SPRINGCRAFT_BULGE_PERSISTENT=2
+run SPRINGCRAFT_GEMM_NO_LOWER_GRID=1 SPRINGCRAFT_GEMM_NO_BALANCE=1 SPRINGCRAFT_GEMM_NO_PAIR=1
+run SPRINGCRAFT_GEMM2_TILE=3
+run SPRINGCRAFT_GEMM2_TILE=1
+run SPRINGCRAFT_GEMM_OLD=1
+run SPRINGCRAFT_BT2_OLD=1
+run SPRINGCRAFT_BT2_NW=4
+run SPRINGCRAFT_NO_AUX=1
+run SPRINGCRAFT_QR_UNBLOCKED=1
