@@ -1963,7 +1963,11 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       }
     }
     static const int env_streams = [] { const char* e = getenv("SPRINGCRAFT_BULGE_STREAMS"); return e ? atoi(e) : 0; }();
-    const int nparts = std::max(1, std::min(env_streams > 0 ? env_streams : (batch >= 16 ? 2 : 1), std::min(batch, 8)));
+    // (three parts from 48 matrices on: 477 -> 431 ms at 64; four and more exceed the ~11 us per launch one host thread
+    // needs -- the stage then takes 48 k launches x 11.4 us --, and replaying the launches as a captured hipGraph is slower
+    // still: 569 ms with three parts)
+    const int nparts = std::max(1, std::min(env_streams > 0 ? env_streams : (batch >= 48 ? 3 : (batch >= 16 ? 2 : 1)),
+                                            std::min(batch, 8)));
     if (!chased) t_bulge.start();
     if (chased) {
     } else if (nparts > 1) {
