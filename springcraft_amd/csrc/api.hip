@@ -10,6 +10,7 @@
 #include <utility>
 
 #include "common.h"
+#include "host_logic.h"
 
 int sc_set_error(sc_ctx* ctx, int code, const char* fmt, ...) {
   char buf[1024];
@@ -112,18 +113,9 @@ int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
 }
 
 int check_ff(sc_ctx* ctx, const sc_ff_desc* ff) {
-  if (!ff) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "force-field descriptor is NULL");
-  if (ff->kind < SC_FF_INVARIANT || ff->kind > SC_FF_TABULATED)
-    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "unknown force-field kind %d", ff->kind);
-  if (ff->kind == SC_FF_TABULATED) {
-    const sc_tab_desc* t = ff->tab;
-    if (!t || t->n_bins < 1 || !t->bonded || !t->intra_chain || !t->inter_chain || !t->atom_type || !t->chain ||
-        !t->bonded_next || (t->n_bins > 1 && !t->edges_sq))
-      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "incomplete tabulated force-field descriptor");
-  }
-  if (ff->kind == SC_FF_INVARIANT && !ff->has_cutoff)
-    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "Cutoff distance must be a float");  // forcefield.py:277-281
-  return SC_OK;
+  std::string err;
+  const int rc = sc_host::check_ff(ff, err);
+  return rc == SC_OK ? SC_OK : sc_set_error(ctx, rc, "%s", err.c_str());
 }
 
 struct Bump {  // carves sub-buffers out of ctx->scratch
@@ -138,83 +130,12 @@ struct Bump {  // carves sub-buffers out of ctx->scratch
   }
 };
 
-struct HostPatch {
-  bool any = false;
-  std::vector<uint8_t> shut;
-  std::vector<int32_t> row_ptr, col;
-  std::vector<int8_t> flag;
-  std::vector<double> gam;
-  int mask_gamma = 0;
-  size_t device_bytes() const {
-    return align_up(shut.size(), 256) + align_up(row_ptr.size() * 4, 256) +
-           align_up(col.size() * 4 + 4, 256) + align_up(flag.size() + 1, 256) +
-           align_up(gam.size() * 8 + 8, 256) + 2048;
-  }
-};
+using sc_host::HostPatch;
 
-// Restates _patch_adjacency_matrix (interaction.py:193-213) + the patch-matrix construction of
-// PatchedForceField.force_constant (forcefield.py:199-224) as a per-row override table.
 int build_patch(sc_ctx* ctx, const sc_patch_desc* pd, int64_t n, HostPatch& hp) {
-  hp.any = false;
-  if (!pd || (pd->n_shutdown == 0 && pd->n_pair_off == 0 && pd->n_pair_on == 0)) return SC_OK;
-  if (pd->n_shutdown < 0 || pd->n_pair_off < 0 || pd->n_pair_on < 0 ||
-      (pd->n_shutdown && !pd->shutdown) || (pd->n_pair_off && !pd->pair_off) ||
-      (pd->n_pair_on && !pd->pair_on))
-    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "inconsistent patch descriptor");
-  hp.any = true;
-  hp.mask_gamma = pd->base_cutoff_masks_gamma;
-  hp.shut.assign((size_t)n, 0);
-  auto in_range = [&](int64_t v) { return v >= 0 && v < n; };
-  for (int64_t s = 0; s < pd->n_shutdown; ++s) {
-    if (!in_range(pd->shutdown[s]))
-      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
-                          (long long)pd->shutdown[s], (long long)n);
-    hp.shut[(size_t)pd->shutdown[s]] = 1;
-  }
-  struct Ov { int8_t flag; double gam; };
-  std::map<std::pair<int32_t, int32_t>, Ov> ov;
-  auto touch = [&](int64_t i, int64_t j) -> Ov& {
-    auto key = std::make_pair((int32_t)i, (int32_t)j);
-    auto it = ov.find(key);
-    if (it == ov.end()) it = ov.emplace(key, Ov{0, -1.0}).first;
-    return it->second;
-  };
-  for (int64_t p = 0; p < pd->n_pair_off; ++p) {
-    const int64_t i = pd->pair_off[2 * p], j = pd->pair_off[2 * p + 1];
-    if (!in_range(i) || !in_range(j))
-      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
-                          (long long)(in_range(i) ? j : i), (long long)n);
-    touch(i, j).flag = 0;
-    touch(j, i).flag = 0;
-  }
-  for (int64_t p = 0; p < pd->n_pair_on; ++p) {
-    const int64_t i = pd->pair_on[2 * p], j = pd->pair_on[2 * p + 1];
-    if (!in_range(i) || !in_range(j))
-      return sc_set_error(ctx, SC_ERR_INDEX, "Index %lld is out of bounds for a structure of length %lld",
-                          (long long)(in_range(i) ? j : i), (long long)n);
-    if (i == j)
-      return sc_set_error(ctx, SC_ERR_SELF_PAIR, "Cannot turn on interaction of an atom with itself");
-  }
-  // numpy assignment order: matrix[i, j] = v for all rows, then matrix[j, i] = v for all rows
-  for (int pass = 0; pass < 2; ++pass)
-    for (int64_t p = 0; p < pd->n_pair_on; ++p) {
-      const int64_t i = pd->pair_on[2 * p + pass], j = pd->pair_on[2 * p + 1 - pass];
-      Ov& o = touch(i, j);
-      o.flag = 1;
-      if (pd->on_force_constants) o.gam = pd->on_force_constants[p];
-    }
-  hp.row_ptr.assign((size_t)n + 1, 0);
-  for (auto& kv : ov) hp.row_ptr[(size_t)kv.first.first + 1]++;
-  for (int64_t i = 0; i < n; ++i) hp.row_ptr[i + 1] += hp.row_ptr[i];
-  hp.col.reserve(ov.size());
-  hp.flag.reserve(ov.size());
-  hp.gam.reserve(ov.size());
-  for (auto& kv : ov) {  // std::map iterates sorted by (i, j): already CSR order
-    hp.col.push_back(kv.first.second);
-    hp.flag.push_back(kv.second.flag);
-    hp.gam.push_back(kv.second.gam == -1.0 ? std::nan("") : kv.second.gam);  // forcefield.py:221-224
-  }
-  return SC_OK;
+  std::string err;
+  const int rc = sc_host::build_patch(pd, n, hp, err);
+  return rc == SC_OK ? SC_OK : sc_set_error(ctx, rc, "%s", err.c_str());
 }
 
 int upload_patch(sc_ctx* ctx, const HostPatch& hp, Bump& bump, PatchDev& dev) {

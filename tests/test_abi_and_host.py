@@ -208,3 +208,26 @@ def test_pdb_adaptor_and_residue_masses():
     # masses=True uses the free amino-acid masses (what biotite's info.mass(res_name, is_residue=True) reports)
     assert anm.masses.shape == (20,)
     assert anm.masses[0] == pytest.approx(132.118) and anm.masses[9] == pytest.approx(75.067)   # ASN, GLY
+
+
+def test_host_logic_under_sanitizers(tmp_path):
+    """
+    SURVEY section 5: sanitizers on the CPU build only.  The HIP-free host logic of the C ABI (contact-patch override
+    table, force-field descriptor checks: csrc/host_logic.h, included by api.hip) compiled with g++ under ASan + UBSan
+    and driven through its edge cases (tests/host_sanitize/test_host_logic.cpp).
+    """
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "test_host_logic")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", join(ROOT, "include"), "-I", join(ROOT, "springcraft_amd", "csrc"),
+           join(ROOT, "tests", "host_sanitize", "test_host_logic.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "ubsan" in r.stderr.lower()) and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtimes not installed")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "host logic ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
