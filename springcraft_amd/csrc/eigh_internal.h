@@ -25,7 +25,7 @@ struct TriLayout {
 // v_c (explicit leading 1) in rows c+1.., and ws holds d, e, tau.
 // NumPy (row-major) lower triangle -> column-major lower triangle, in place
 int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch);
-// mirror + scaling of badly scaled matrices (largest |entry| outside [1e-140, 1e140]) by a power of two; the factor
+// mirror + scaling of badly scaled matrices (largest |entry| outside [1e-100, 1e100]) by a power of two; the factor
 // stays in the tri slab and unscale_values_batched divides the computed eigenvalues by it.  Call before
 // tridiag_batched / sytrd_2stage_batched (neither mirrors by itself).
 int prepare_matrix_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_tri_ws,

@@ -68,9 +68,14 @@ __global__ void k_dc_prepare(const double* __restrict__ tri_all, TriLayout TL, d
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mx = fmax(mx, red[w]);
   const double nrm = (mx > 0.0 && mx == mx) ? mx : 1.0;
   const double inv = 1.0 / nrm;
+  // entries below 1e-150 of the norm are flushed to zero: they cannot change a double-precision result, and kept they
+  // would drag the merges into denormal arithmetic (z^2, vector norms) -- a graded tridiagonal matrix of that kind comes
+  // out of exactly rank-deficient input such as ones(n, n)
   for (int i = tid; i < n; i += blockDim.x) {
-    ws[DL.dd + i] = tri[TL.d + i] * inv;
-    ws[DL.ee + i] = (i < n - 1) ? tri[TL.e + i] * inv : 0.0;
+    const double dv = tri[TL.d + i] * inv;
+    const double ev = (i < n - 1) ? tri[TL.e + i] * inv : 0.0;
+    ws[DL.dd + i] = fabs(dv) < 1e-150 ? 0.0 : dv;
+    ws[DL.ee + i] = fabs(ev) < 1e-150 ? 0.0 : ev;
   }
   if (tid == 0) ws[DL.scale] = nrm;
   __syncthreads();

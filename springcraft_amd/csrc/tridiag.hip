@@ -41,7 +41,12 @@ struct HH {
 // LAPACK dlarfg scalars for alpha = a[c+1], xn2 = ||a[c+2:]||^2
 __device__ __forceinline__ HH householder(double alpha, double xn2) {
   HH h;
-  if (xn2 == 0.0) {
+  // No reflection either when the column (pivot included) is below 1e-140: its squares are in the underflow range, where
+  // a norm is not a norm any more (LAPACK's dlarfg rescales there) and the reflector would come out non-orthogonal.  The
+  // input is scaled to [1e-100, 1e100] (matrix_scale_factor), so such a column is < 1e-40 of the matrix: the caller
+  // stores zeros for its tail, a backward error far below rounding.  Seen with exactly rank-deficient input such as
+  // ones(n, n), whose trailing matrices shrink by a factor eps per column.
+  if (xn2 == 0.0 || alpha * alpha + xn2 < 1e-280) {
     h.beta = alpha; h.tau = 0.0; h.scale = 0.0;
     return h;
   }
@@ -445,7 +450,7 @@ __global__ void k_mirror_lower(double* __restrict__ a_all, long long stride_a, i
 }
 
 // ---- scaling of badly scaled matrices (what LAPACK dsyevd does with dlansy / dlascl) -------------------------------
-// The Householder norms square the entries, so a matrix whose largest |entry| is outside [1e-140, 1e140] is multiplied
+// The Householder norms square the entries, so a matrix whose largest |entry| is outside [1e-100, 1e100] is multiplied
 // by a power of two that brings it to ~1 (exact), and the eigenvalues are divided by it afterwards.  Everything is
 // decided on the device: amax -> factor -> conditional in-place scaling, no host synchronisation.
 __global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__ a_all, long long stride_a, int n,
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__
 
 __device__ __forceinline__ double matrix_scale_factor(double amax) {
   if (!(amax > 0.0) || amax > 1.7e308) return 1.0;
-  if (amax >= 1e-140 && amax <= 1e140) return 1.0;
+  if (amax >= 1e-100 && amax <= 1e100) return 1.0;
   return ldexp(1.0, -ilogb(amax));
 }
 

@@ -39,7 +39,12 @@ struct HH {
 // LAPACK dlarfg scalars: x = (alpha, tail), xn2 = ||tail||^2;  H x = beta e1,  v = (1, scale * tail)
 __device__ __forceinline__ HH householder(double alpha, double xn2) {
   HH h;
-  if (xn2 == 0.0) {
+  // No reflection either when the column (pivot included) is below 1e-140: its squares are in the underflow range, where
+  // a norm is not a norm any more (LAPACK's dlarfg rescales there) and the reflector would come out non-orthogonal.  The
+  // input is scaled to [1e-100, 1e100] (matrix_scale_factor), so such a column is < 1e-40 of the matrix: the caller
+  // stores zeros for its tail, a backward error far below rounding.  Seen with exactly rank-deficient input such as
+  // ones(n, n), whose trailing matrices shrink by a factor eps per column.
+  if (xn2 == 0.0 || alpha * alpha + xn2 < 1e-280) {
     h.beta = alpha; h.tau = 0.0; h.scale = 0.0;
     return h;
   }

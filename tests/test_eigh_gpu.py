@@ -321,3 +321,31 @@ def test_badly_scaled_matrices(sc, scale):
             assert np.abs(ws / scale - w_ref[10:21]).max() <= 1e-11 * np.abs(w_ref).max()
     finally:
         ctx.set_two_stage(None)
+
+
+@pytest.mark.parametrize("two_stage", [False, True])
+@pytest.mark.parametrize("n", [640, 1000])
+def test_exactly_rank_deficient_input(two_stage, n):
+    """
+    ones(n, n) and relatives: the trailing matrices of the reduction are pure rounding residue that shrinks by a factor
+    eps per column, down into the range where squares underflow (round 2: reflectors built from such columns were not
+    orthogonal; n = 1000 on the one-stage path returned vectors of norm 0.76).  Gates of SURVEY 8(d).
+    """
+    import springcraft_amd as sc
+    from springcraft_amd import _hip
+
+    ctx = _hip.context()
+    ctx.set_two_stage(two_stage)
+    try:
+        blocks = np.zeros((n, n))
+        blocks[: n // 2, : n // 2] = 1.0
+        blocks[n // 2:, n // 2:] = 3.0
+        for a in (np.ones((n, n)), 1e-120 * np.ones((n, n)), 1e130 * np.ones((n, n)), blocks):
+            w, v = sc.nma.eigh(a)
+            w_ref = np.linalg.eigvalsh(a)
+            scale = np.abs(w_ref).max()
+            assert np.abs(w - w_ref).max() <= 1e-12 * scale
+            assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-12 * scale
+            assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-12
+    finally:
+        ctx.set_two_stage(None)
