@@ -215,6 +215,8 @@ class Context:
             raise IndexError(msg)
         if rc == SC_ERR_NOMEM:
             raise MemoryError(msg)
+        if rc == SC_ERR_NOCONV:   # what np.linalg.eigh raises at nma.py:61 (non-finite input, no convergence)
+            raise np.linalg.LinAlgError(msg)
         raise RuntimeError(f"springcraft_hip: {msg} (status {rc})")
 
     def synchronize(self):

@@ -458,14 +458,23 @@ __global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__
   const double* A = a_all + (size_t)blockIdx.y * stride_a;
   unsigned long long* slot = reinterpret_cast<unsigned long long*>(ws_all + (size_t)blockIdx.y * L.slab + L.hscale + 1);
   double m = 0.0;
+  int bad = 0;
   const size_t total = (size_t)n * n;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
-    if (r >= c) m = fmax(m, fabs(A[idx]));   // fmax drops NaNs: they stay in the matrix and surface in the result
+    if (r >= c) {
+      const double x = fabs(A[idx]);
+      m = fmax(m, x);                       // (fmax drops NaNs)
+      bad |= !(x <= 1.7976931348623157e308);   // NaN or Inf
+    }
   }
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
   // the bit patterns of non-negative doubles are ordered like the values
   if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, (unsigned long long)__double_as_longlong(m));
+  // a matrix with a NaN / Inf entry must not reach the solver (comparisons with NaN would drive its index arithmetic):
+  // its number + 1 goes to the flag in the FIRST matrix's slab, which prepare_matrix_batched reads back
+  if (__any(bad) && (threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(ws_all + L.hscale + 3), (unsigned long long)blockIdx.y + 1ull);
 }
 
 __device__ __forceinline__ double matrix_scale_factor(double amax) {
@@ -512,11 +521,17 @@ int prepare_matrix_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, 
   SC_TRY(mirror_lower_batched(ctx, d_a, stride_a, n, batch));
   hipStream_t st = ctx->stream;
   for (int b = 0; b < batch; ++b)
-    SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * L.slab + L.hscale + 1, 0, 2 * sizeof(double), st));
+    SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * L.slab + L.hscale + 1, 0, 3 * sizeof(double), st));
   const unsigned gx = (unsigned)std::min<size_t>(1024, ((size_t)n * n + 255) / 256);
   hipLaunchKernelGGL(k_absmax_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
+  unsigned long long h_bad = 0;
+  SC_HIP(ctx, hipMemcpyAsync(&h_bad, d_tri_ws + L.hscale + 3, sizeof(h_bad), hipMemcpyDeviceToHost, st));
   hipLaunchKernelGGL(k_scale_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
   SC_HIP(ctx, hipGetLastError());
+  SC_HIP(ctx, hipStreamSynchronize(st));
+  if (h_bad)   // np.linalg.eigh raises LinAlgError("Eigenvalues did not converge") for such input (nma.py:61)
+    return sc_set_error(ctx, SC_ERR_NOCONV, "Eigenvalues did not converge: matrix %llu of the batch contains NaN or Inf",
+                        h_bad - 1ull);
   return SC_OK;
 }
 

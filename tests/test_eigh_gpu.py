@@ -349,3 +349,42 @@ def test_exactly_rank_deficient_input(two_stage, n):
             assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-12
     finally:
         ctx.set_two_stage(None)
+
+
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_non_finite_input_is_rejected(two_stage):
+    """NaN / Inf in the matrix: LinAlgError as from np.linalg.eigh (nma.py:61), before any solver kernel sees it."""
+    import springcraft_amd as sc
+    from springcraft_amd import _hip
+
+    ctx = _hip.context()
+    ctx.set_two_stage(two_stage)
+    try:
+        rs = np.random.RandomState(5)
+        a = rs.standard_normal((300, 300))
+        a = a + a.T
+        for bad in (np.nan, np.inf, -np.inf):
+            b = a.copy()
+            b[200, 17] = b[17, 200] = bad
+            with pytest.raises(np.linalg.LinAlgError):
+                sc.nma.eigh(b)
+            with pytest.raises(np.linalg.LinAlgError):
+                sc.nma.eigh(b, eigenvectors=False)
+            with pytest.raises(np.linalg.LinAlgError):
+                sc.nma.eigh(b, subset_by_index=(0, 9))
+        # the context is still usable and the upper triangle is not read (UPLO = 'L')
+        c = a.copy()
+        c[17, 200] = np.nan
+        w, v = sc.nma.eigh(c)
+        assert np.allclose(w, np.linalg.eigvalsh(a), rtol=0, atol=1e-11 * np.abs(w).max())
+        # a NaN coordinate with a cut-off force field only isolates its atom (every comparison with NaN is false, as in
+        # interaction.py:166): the Hessian stays finite, with three more zero modes
+        coord = synthetic_coord(60, 1)
+        coord[7, 1] = np.nan
+        w = sc.ANM(coord, sc.InvariantForceField(13.0)).eigen()[0]
+        assert np.isfinite(w).all() and np.abs(w[:9]).max() <= 1e-9 * w.max() and w[9] > 1e-6 * w.max()
+        # without a cut-off the NaN reaches the Hessian
+        with pytest.raises(np.linalg.LinAlgError):
+            sc.ANM(coord, sc.HinsenForceField()).eigen()
+    finally:
+        ctx.set_two_stage(None)

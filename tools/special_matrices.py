@@ -1,3 +1,4 @@
+"""ones(n, n), low rank, clustered spectra, extreme scales through the two-stage path.  python tools/special_matrices.py"""
 import numpy as np, sys
 sys.path.insert(0, ".")
 import springcraft_amd as sc
