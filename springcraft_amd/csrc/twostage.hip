@@ -17,6 +17,7 @@
 //
 // Role in the reference: part of np.linalg.eigh (LAPACK dsyevd) at nma.py:61; LAPACK itself uses the one-stage dsytrd.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <vector>
 
@@ -808,7 +809,8 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
             const int need = min(k + 2, len_prev);
             long spins = 0;
             while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-              if (++spins > (1L << 21) || __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              // (2^18 polls of ~1 us: a quarter of a second, orders of magnitude above any wait among resident workgroups)
+              if (++spins > (1L << 18) || __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 go = 0;
                 break;
@@ -1904,7 +1906,11 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // n = 12000 matrix chases 1.5 x faster with its ~94 tasks per wavefront spread over the whole chip
     const bool want_chase = env_persist == 2 ||
                             (env_persist == 1 && (long long)batch * n / 128 <= 1200 && (batch >= 8 || n <= 6144));
-    if (want_chase && ctx->num_cus > 0 && ctx->num_cus % 8 == 0 && ctx->chase_ok != 0) {
+    // a chase that ran into its time-out once (the GPU is shared, not all workgroups were resident) is not tried again
+    // in this process: every further attempt would cost another time-out before the fallback
+    static std::atomic<int> chase_gave_up{0};
+    if (want_chase && ctx->num_cus > 0 && ctx->num_cus % 8 == 0 && ctx->chase_ok != 0 &&
+        (env_persist == 2 || !chase_gave_up.load())) {
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
       if (ctx->chase_ok < 0 && per_cu > 0) {   // once per context: does a chip-filling launch give every XCD its share?
@@ -1954,6 +1960,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
             // resident).  Workgroups only stop between tasks and every finished task is published, so the counters
             // describe a consistent state: the per-wavefront launches finish the chase, skipping what is done.
             ctx->chase_ok = 0;
+            chase_gave_up.store(1);
             const int t_max2 = 2 * (n - 3) + chase_len(n, n - 3) - 1;
             for (int t = 0; t <= t_max2; ++t)
               hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)(chase_len(n, 0) / 2 + 1), (unsigned)batch), dim3(256), 0, st,
