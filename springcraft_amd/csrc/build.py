@@ -20,7 +20,7 @@ OBJ = join(HERE, "obj")
 LIB = join(PKG, "libspringcraft_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Werror=return-type",
           "-I", join(REPO, "include")] + os.environ.get("SC_EXTRA_HIPCC_FLAGS", "").split()
 PER_FILE = {
     "assembly.hip": ["-ffp-contract=off"],

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
                                                    long long gscratch_stride) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[16];
-  __shared__ double s_tol, s_rho;
+  __shared__ double s_tol;
   const int g = blockIdx.x, b = blockIdx.y;
   const DcNode nd = nodes[g];
   double* ws = dc_all + (size_t)b * DL.slab;
@@ -268,7 +268,6 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
     double mx = 0.0;
     for (int w = 0; w < (nthr >> 6); ++w) mx = fmax(mx, red[w]);
     s_tol = 8.0 * kEps * mx;
-    s_rho = rho;
   }
   __syncthreads();
   // stable merge of the two ascending child spectra by rank

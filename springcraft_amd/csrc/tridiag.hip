@@ -612,6 +612,5 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
     }
   }
   SC_HIP(ctx, hipGetLastError());
-  if (prof)
   return SC_OK;
 }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
   double* P = sm;                      // [kB - c0][LD]: columns c0 .. kB-1, indexed relative to c0
   double* vv = sm + (kB - c0) * LD;    // [kQrRows]
   double* red = vv + kQrRows;          // [4][2][kB]
-  __shared__ double s_scale, s_beta, s_tau;
+  __shared__ double s_scale, s_beta;
   const int n = TL.n;
   const int r0 = j0 + kB, m = n - r0;
   double* A = a_all + (size_t)blockIdx.y * stride_a;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
     __syncthreads();
     if (tid == 0) {
       const HH h = householder(piv_in[prev], (red[0] + red[1]) + (red[2] + red[3]));
-      s_scale = h.scale; s_beta = h.beta; s_tau = h.tau;
+      s_scale = h.scale; s_beta = h.beta;
       if (chunk == 0) tri[TL.tau + j0 + prev] = h.tau;
     }
   }
