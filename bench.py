@@ -282,9 +282,9 @@ def run_c3(args, rank, world, torch, dist):
                     "kernel": "k_bulge_step", "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(bw / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": bb,
                     "what": "stage 2 (band -> tridiagonal): every task reads and writes its off-diagonal block and the lower "
-                            "triangle of its diagonal block / wall time of the stage (HIP events; its launches run as two "
-                            "halves of the batch on two streams, so per-kernel durations in a rocprof summary overlap and "
-                            "add up to more than this)",
+                            "triangle of its diagonal block / wall time of the stage (HIP events; its launches run as "
+                            "parts of the batch on separate streams, so per-kernel durations in a rocprof summary overlap "
+                            "and add up to more than this)",
                 }
         else:
             launches = (n - 2)
