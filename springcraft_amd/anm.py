@@ -2,8 +2,6 @@
 :class:`ANM` — Anisotropic Network Model (host mirror of the reference's anm.py:20-445).
 """
 
-import numpy as np
-
 from . import nma
 from ._model import ElasticNetworkModel
 

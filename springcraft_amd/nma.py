@@ -10,7 +10,6 @@ eigenpairs (``csrc/consumers.hip``): the (n, n) eigenvector matrix never crosses
 results that are already on the host.
 """
 
-import ctypes as C
 
 import numpy as np
 
