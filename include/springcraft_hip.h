@@ -198,9 +198,9 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
 int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
                           double* d_w, double* d_v);
 
-/* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when batch * n^2 >= 1.2e8 and
- * n >= 512, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the same eigenpairs to
- * rounding (|dw| ~ 1e-14 |w|max); the choice only affects speed. */
+/* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when n >= 1024 and
+ * batch * n^2 >= 5e7 + 6.7e3 n, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the
+ * same eigenpairs to rounding (|dw| ~ 1e-14 |w|max); the choice only affects speed. */
 int sc_ctx_set_two_stage(sc_ctx* ctx, int mode);
 
 /* Bytes of device workspace sc_dev_eigh_f64 will hold for (n, batch) (allocated lazily, cached). */
@@ -219,6 +219,19 @@ int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
  * "dc_gemm" (its merge GEMMs), "bt2" (stage-2 back-transformation), "bt1_w" / "bt1_update" (the two GEMMs of the stage-1
  * back-transformation).  Unknown names (or phases the last solve did not run): SC_ERR_INVALID_ARG, *ms = 0. */
 int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
+
+/* Event counters of the context since it was created (monitoring; nothing in the reference corresponds).  Names:
+ *   "chase_launches"   persistent bulge chases started (two-stage path, latency-bound batches)
+ *   "chase_timeouts"   of those, how many ran into the bound of an inter-workgroup wait -- expected to stay 0; the
+ *                      solve is still finished correctly by the per-wavefront launches ("chase_resumed" counts every
+ *                      such take-over, "chase_incomplete" a chase that ended without a flag but with sweeps left),
+ *                      and the context stops using the persistent form
+ *   "chase_sweeps"     sweeps the persistent chases finished themselves
+ *   "stepwise_chases"  bulge chases that ran as per-wavefront launches from the start
+ *   "chase_xcd_min" / "chase_xcd_max"   workgroups per XCD in the most recent persistent chase
+ *   "chase_wait_matrix" / "_sweep" / "_task"   where the last timed-out wait stood (-1: never)
+ * Unknown names: SC_ERR_INVALID_ARG, *value = 0. */
+int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value);
 
 /* ---- device-resident eigenpairs and their consumers ----------------------------------
  * An sc_modes object holds all n eigenvalues and eigenvectors of one model's Kirchhoff (dim 1) or Hessian

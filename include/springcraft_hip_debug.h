@@ -50,6 +50,12 @@ int sc_dbg_bt2_stamps(unsigned long long* out);
  * with k > 0], until the diagonal block D is in LDS, until the end; tasks; tasks with k > 0}.  tools/bulge_stamps.py */
 int sc_dbg_bulge_stamps(unsigned long long* out6);
 
+/* Persistent bulge chase of this context: mode -1 = SPRINGCRAFT_BULGE_PERSISTENT or the size rule (default), 0 never,
+ * 1 by size, 2 always.  give_up_after > 0: test hook, every workgroup of the chase raises the time-out flag after that
+ * many tasks, which forces the take-over by the per-wavefront launches (counted in "chase_resumed", not in
+ * "chase_timeouts").  tests/test_two_stage_gpu.py */
+int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after);
+
 #ifdef __cplusplus
 }
 #endif

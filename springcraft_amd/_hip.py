@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
     "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
     "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage", "sc_last_eigh_phase_ms",
+    "sc_ctx_get_counter",
 ]
 
 
@@ -162,6 +163,7 @@ def lib():
         "sc_ctx_set_two_stage": (i32, [vp, i32]),
         "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
         "sc_last_eigh_phase_ms": (i32, [vp, C.c_char_p, P(dbl)]),
+        "sc_ctx_get_counter": (i32, [vp, C.c_char_p, P(i64)]),
         "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
         "sc_modes_from_matrix": (i32, [vp, vp, i64, i32, P(vp)]),
         "sc_modes_destroy": (None, [vp]),
@@ -225,6 +227,13 @@ class Context:
     def set_two_stage(self, mode):
         """Eigensolver path: None / -1 automatic, False / 0 one-stage, True / 1 two-stage tridiagonalisation."""
         self.check(self._L.sc_ctx_set_two_stage(self._h, -1 if mode is None else int(mode)))
+
+    def counter(self, name):
+        """Event counter of this context (``sc_ctx_get_counter``), e.g. ``"chase_timeouts"``."""
+        v = C.c_int64(0)
+        if self._L.sc_ctx_get_counter(self._h, name.encode(), C.byref(v)) != SC_OK:
+            raise ValueError(f"no counter named {name!r}")
+        return int(v.value)
 
     def info(self):
         buf = C.create_string_buffer(256)

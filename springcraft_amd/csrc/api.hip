@@ -307,8 +307,41 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms) {
   if (!ctx || !name || !ms) return SC_ERR_INVALID_ARG;
   for (const auto& p : ctx->phases)
     if (p.first == name) { *ms = p.second; return SC_OK; }
+  // a phase the last solve did not run is an answer, not a failure: the context's error string is left alone
   *ms = 0.0;
-  return sc_set_error(ctx, SC_ERR_INVALID_ARG, "no phase named '%s' in the last profiled eigensolve", name);
+  return SC_ERR_INVALID_ARG;
+}
+
+int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
+  if (!ctx || !name || !value) return SC_ERR_INVALID_ARG;
+  const std::string k(name);
+  int tmin = ctx->chase_tickets[0], tmax = ctx->chase_tickets[0];
+  for (int x = 1; x < 8; ++x) {
+    tmin = std::min(tmin, ctx->chase_tickets[x]);
+    tmax = std::max(tmax, ctx->chase_tickets[x]);
+  }
+  if (k == "chase_launches") *value = ctx->cnt_chase_launches;
+  else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
+  else if (k == "chase_incomplete") *value = ctx->cnt_chase_incomplete;
+  else if (k == "chase_resumed") *value = ctx->cnt_chase_resumed;
+  else if (k == "chase_sweeps") *value = ctx->cnt_chase_sweeps;
+  else if (k == "stepwise_chases") *value = ctx->cnt_stepwise_chases;
+  else if (k == "chase_xcd_min") *value = tmin;
+  else if (k == "chase_xcd_max") *value = tmax;
+  else if (k == "chase_wait_matrix") *value = ctx->chase_wait[0];
+  else if (k == "chase_wait_sweep") *value = ctx->chase_wait[1];
+  else if (k == "chase_wait_task") *value = ctx->chase_wait[2];
+  else { *value = 0; return SC_ERR_INVALID_ARG; }
+  return SC_OK;
+}
+
+// debugging entry point (include/springcraft_hip_debug.h)
+int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after) {
+  if (!ctx || mode < -1 || mode > 2 || give_up_after < 0) return SC_ERR_INVALID_ARG;
+  ctx->chase_mode = mode;
+  ctx->chase_give_up = give_up_after;
+  if (mode >= 0) ctx->chase_ok = -1;
+  return SC_OK;
 }
 
 int sc_contacts(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,

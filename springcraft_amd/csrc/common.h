@@ -38,7 +38,16 @@ struct sc_ctx {
   size_t dc_aux_bytes = 0;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
-  int chase_ok = -1;    // persistent bulge chase usable on this device: -1 not probed yet, 0 no, 1 yes (twostage.hip)
+  // persistent bulge chase (twostage.hip): chase_ok = 0 once a chase of this context ran into its time-out (never
+  // expected; the per-wavefront launches take over from then on); chase_mode / chase_give_up are set through the debug
+  // entry sc_dbg_set_chase (-1: SPRINGCRAFT_BULGE_PERSISTENT or the size rule; 0 / 1 / 2 as that variable).
+  int chase_ok = -1;
+  int chase_mode = -1, chase_give_up = 0;
+  // event counters since the context was created (sc_ctx_get_counter)
+  long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
+            cnt_chase_sweeps = 0, cnt_stepwise_chases = 0;
+  int chase_tickets[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroups per XCD of the most recent chase launch
+  int chase_wait[3] = {-1, -1, -1};                  // (matrix, sweep, task) of the wait that timed out last
   bool profiling = false;
   double last_timings[6] = {0, 0, 0, 0, 0, 0};
   // named kernel-group durations of the most recent profiled eigensolve (sc_last_eigh_phase_ms)

@@ -330,10 +330,20 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   GemmDesc* descs = (GemmDesc*)(base + off_desc);
 
   std::vector<GemmDesc> h((size_t)npanels * batch);
+  // profiled solve: [0] tridiagonalisation, [1] bisection + inverse iteration, [2] back-transformation, and as in
+  // eigh_batched [3] / [4] = band reduction / bulge chasing (two-stage) or SYMV / SYR2K sums, [5] = k_bt2_apply
+  ScopedEvents<4> ev;
+  const bool prof = ctx->profiling;
+  float ms_a = 0.f, ms_b = 0.f, ms_bt2 = 0.f;
+  if (prof) {
+    ctx->phases.clear();
+    for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
+    SC_HIP(ctx, hipEventRecord(ev[0], st));
+  }
   SC_TRY(prepare_matrix_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL));
   if (two) {
     SC_TRY(sytrd_2stage_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, sb_ws, SL, (int*)(base + off_dia), descs,
-                                nullptr, nullptr));
+                                &ms_a, &ms_b));
   } else {
     for (int p = 0; p < npanels; ++p) {
       const int pend = std::min((p + 1) * kNb, n);
@@ -350,24 +360,44 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
       }
     }
     SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
-    float ms_symv = 0.f, ms_syr2k = 0.f;
-    SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_symv, &ms_syr2k));
+    SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_a, &ms_b));
   }
+  if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
   GemmDesc* d2 = descs + (size_t)n_tri_desc;
   if (!d_v) {
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, nullptr, 0, nullptr, d2));
     SC_TRY(unscale_values_batched(ctx, d_w, m, m, batch, tri_ws, TL));
+    if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
   } else {
     const long long stride_x = (long long)n * m;
     SC_TRY(stein_batched(ctx, n, batch, tri_ws, TL, il, iu, d_w, m, d_v, stride_x, (double*)(base + off_stein), d2));
     SC_TRY(unscale_values_batched(ctx, d_w, m, m, batch, tri_ws, TL));
+    if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
     if (two) {
+      PhaseTimer t_tf(ctx, "dia_tfactor", st);
+      t_tf.start();
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, SL, st));
-      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m));
+      t_tf.stop();
+      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, SL, (const int*)(base + off_dia), d_v, stride_x, m, &ms_bt2));
+      t_tf.finish();
     }
     // the back-transformation indexes its scratch with the matrix stride: VT lives in an n x n buffer per matrix
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, (double*)(base + off_bt), BL, d_v,
                                  stride_x, m, (double*)(base + off_vt), d2 + 2 * batch, two ? sb_band_width() : 1));
+  }
+  if (prof) {
+    SC_HIP(ctx, hipEventRecord(ev[3], st));
+    SC_HIP(ctx, hipEventSynchronize(ev[3]));
+    float t01 = 0, t12 = 0, t23 = 0;
+    SC_HIP(ctx, hipEventElapsedTime(&t01, ev[0], ev[1]));
+    SC_HIP(ctx, hipEventElapsedTime(&t12, ev[1], ev[2]));
+    SC_HIP(ctx, hipEventElapsedTime(&t23, ev[2], ev[3]));
+    ctx->last_timings[0] = t01;
+    ctx->last_timings[1] = t12;
+    ctx->last_timings[2] = t23;
+    ctx->last_timings[3] = ms_a;
+    ctx->last_timings[4] = ms_b;
+    ctx->last_timings[5] = two ? (d_v ? ms_bt2 : 1e-9) : 0.0;
   }
   SC_HIP(ctx, hipStreamSynchronize(st));
   return SC_OK;

@@ -17,7 +17,6 @@
 //
 // Role in the reference: part of np.linalg.eigh (LAPACK dsyevd) at nma.py:61; LAPACK itself uses the one-stage dsytrd.
 #include <algorithm>
-#include <atomic>
 #include <cstdlib>
 #include <vector>
 
@@ -742,58 +741,82 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Persistent form of the bulge chase: ONE launch, no launch per wavefront.  Workgroup (matrix b, lane r of W) takes the
-// sweeps s = r, r + W, ... of its matrix and walks each of them down the band, task after task; task (s, k) starts when
-// sweep s - 1 has published k + 2 finished tasks (progress[b][s - 1], one counter per sweep), which is the only
-// dependence the chase has.  The previous reflector of the sweep stays in LDS (no round trip through the diamond
-// storage), a sweep never waits for a launch boundary, and the matrices drift apart freely, so no round of workgroups is
-// left half empty.
+// Persistent form of the bulge chase: ONE launch, no launch per wavefront.  A workgroup CLAIMS the next unclaimed sweep
+// of a matrix (an atomic counter per matrix) and walks it down the band, task after task; task (s, k) starts when sweep
+// s - 1 has published k + 2 finished tasks (progress[b][s - 1], one counter per sweep), which is the only dependence
+// the chase has.  The previous reflector of the sweep stays in LDS (no round trip through the diamond storage), a sweep
+// never waits for a launch boundary, and the matrices drift apart freely, so no round of workgroups is left half empty.
 //
-// Coherence without L2 write-backs: all W workgroups of a matrix sit on ONE XCD (matrix b on XCD b mod 8; a workgroup
-// reads the XCD it runs on from XCC_ID and draws its role there), i.e. behind one L2.  A task's stores are drained (vmcnt(0)) and fenced by a workgroup barrier before thread 0
-// publishes the counter; consumers read the counter and the band through agent-scope relaxed atomic loads, which bypass
-// the CU's L1 and are served by that L2 (26 us per hand-off with release / acquire at agent scope, 3 us this way:
-// tools/probe_handoff.hip).  The launch is cooperative (all workgroups resident); every spin is bounded and a time-out
-// raises a flag that ends all workgroups, so the kernel terminates whatever happens (the host then reports an error).
+// Forward progress by construction: sweeps are claimed in order by workgroups that are running, so the owner of sweep
+// s - 1 is always running or finished when somebody waits for it -- whatever the number of resident workgroups and
+// however the dispatcher spreads them over the XCDs.  (Round 2 gave workgroup r of W the sweeps r, r + W, ... statically;
+// a role that was not resident orphaned its sweeps and the successor spun into its bound.)  No cooperative launch and no
+// placement census is needed any more.
+//
+// Coherence without L2 write-backs: all workgroups of a matrix sit on ONE XCD (matrix b on XCD b mod 8; a workgroup
+// reads the XCD it runs on from XCC_ID and only ever touches that XCD's matrices, their claim counters and progress
+// counters), i.e. behind one L2.  A task's stores are drained (vmcnt(0)) and fenced by a workgroup barrier before thread
+// 0 publishes the counter; consumers read the counter and the band through agent-scope relaxed atomic loads, which
+// bypass the CU's L1 and are served by that L2 (26 us per hand-off with release / acquire at agent scope, 3 us this way:
+// tools/probe_handoff.hip).  A workgroup starts on its "home" matrix (ticket mod matrices of the XCD) and moves on to
+// the XCD's other matrices when that one has no unclaimed sweep left, so every matrix of an XCD is finished as long as
+// ONE workgroup lands there.  Every spin is bounded as a last line of defence: a time-out raises a flag that ends all
+// workgroups between tasks; the host counts it (sc_ctx_get_counter "chase_timeouts"), finishes the chase with the
+// per-wavefront launches from the published counters and does not use the persistent form on that context again.
+//
+// ctl (ints): [0] time-out flag, [1] workgroup-local tasks after which the test hook raised it, [2..9] tickets drawn
+// per XCD, [10..12] (matrix, sweep, task) of the wait that timed out, [16..23] sweeps finished per XCD.
+constexpr int kChaseCtlInts = 32;
+
 __device__ __forceinline__ double ld_l2(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
-                                                     int* __restrict__ progress, int* __restrict__ flags,
-                                                     int give_up_after) {
+                                                     int* __restrict__ progress, int* __restrict__ next_sweep,
+                                                     int* __restrict__ ctl, int give_up_after) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
   double* D = E;
   __shared__ double vbuf[2][kB], u[kB], red[4 * kB];
   __shared__ double s_tau, s_beta;
-  __shared__ int s_go;
+  __shared__ int s_go, s_claim;
 
   const int n = SL.n;
   const int tid = threadIdx.x;
   const int i = tid & 63, q = tid >> 6;
-  // Role from the XCD the workgroup really runs on (XCC_ID) and a ticket drawn there: the launch fills the chip
-  // (gridDim.x = resident workgroups per CU x CUs), so every XCD hands out the same gridDim.x / 8 tickets and all W
-  // roles of each of its `groups` matrices in flight are taken.  flags[2 + xcd] are the ticket counters.
   __shared__ int s_xcd, s_slot;
   if (tid == 0) {
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
     s_xcd = (int)(id & 7u);
-    s_slot = atomicAdd(flags + 2 + s_xcd, 1);
+    s_slot = atomicAdd(ctl + 2 + s_xcd, 1);
   }
   __syncthreads();
   const int xcd = s_xcd, slot = s_slot;
-  const int groups = (gridDim.x >> 3) / W;          // matrices in flight per XCD
-  const int grp = slot / W, r = slot % W;
-  if (grp >= groups) return;
+  const int mpx = xcd < batch ? (batch - xcd + 7) / 8 : 0;   // matrices of this XCD: xcd, xcd + 8, ...
+  if (mpx == 0 || slot >= mpx * W) return;                      // no more than W workgroups per matrix
   const int K0 = chase_len(n, 0);
+  int tasks_left = give_up_after;
 
-  for (int b = xcd + 8 * grp; b < batch; b += 8 * groups) {
+  int cur = slot % mpx, exhausted = 0;
+  while (exhausted < mpx) {
+    const int b = xcd + 8 * cur;
+    int* prog = progress + (size_t)b * n;
+    // ---- claim the next sweep of matrix b (the counter is only ever touched from this XCD)
+    if (tid == 0) s_claim = atomicAdd(next_sweep + b, 1);
+    __syncthreads();
+    const int s = s_claim;
+    __syncthreads();
+    if (s > n - 3) {
+      ++exhausted;
+      cur = cur + 1 < mpx ? cur + 1 : 0;
+      continue;
+    }
+    exhausted = 0;
     double* sb = sb_all + (size_t)b * SL.slab;
     double* ab = sb + SL.ab;
-    int* prog = progress + (size_t)b * n;
-    for (int s = r; s <= n - 3; s += W) {
+    {
       const int len = chase_len(n, s);
       const int S = s / kG, cc = s - S * kG;
       const size_t dia0 = (size_t)S * K0 - (size_t)S * (S - 1) / 2;
@@ -804,14 +827,17 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         double* vn = vbuf[k & 1];
         // ---- wait for sweep s - 1
         if (tid == 0) {
-          int go = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
+          int go = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
           if (go && s > 0) {
             const int need = min(k + 2, len_prev);
             long spins = 0;
             while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-              // (2^18 polls of ~1 us: a quarter of a second, orders of magnitude above any wait among resident workgroups)
-              if (++spins > (1L << 18) || __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
+              if (++spins > (1L << 21) || __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                  ctl[10] = b; ctl[11] = s; ctl[12] = k;
+                }
+                __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 go = 0;
                 break;
               }
@@ -934,27 +960,16 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         __syncthreads();
         if (tid == 0) {
           __hip_atomic_store(prog + s, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // test hook (SPRINGCRAFT_BULGE_GIVE_UP): raise the time-out flag after that many tasks of this workgroup
-          if (give_up_after > 0 && --give_up_after == 0)
-            __hip_atomic_store(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (k + 1 == len) atomicAdd(ctl + 16 + xcd, 1);
+          // test hook (sc_dbg_set_chase): raise the time-out flag after that many tasks of this workgroup
+          if (give_up_after > 0 && --tasks_left == 0) {
+            ctl[1] = give_up_after;
+            __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
   }
-}
-
-// Census with the footprint of k_bulge_chase (same block size, same LDS): how many workgroups of a chip-filling launch
-// land on each XCD.  The chase draws its roles per XCD and needs every XCD to receive exactly its share.
-__global__ __launch_bounds__(256) void k_chase_census(int* __restrict__ counts) {
-  __shared__ double pad[kB * (kB + 1) + 2 * kB + kB + 4 * kB + 4];
-  if (threadIdx.x == 0) {
-    unsigned id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-    atomicAdd(counts + (id & 7u), 1);
-    pad[0] = 0.0;
-  }
-  __syncthreads();
-  if (pad[threadIdx.x & 1] != 0.0) counts[8] = 1;   // (keeps the LDS allocation)
 }
 
 // ================================================================================================================
@@ -1896,84 +1911,83 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // The launches of one chase are strictly ordered and every one of them ends with a partly filled last round of
     // workgroups.  Parts of the batch on separate streams run the same launches independently of each other, so the
     // tail of one part's launch is filled by the next launch of another part.
-    // ---- persistent chase (one cooperative launch) when the device places workgroups as the kernel's coherence scheme
-    // assumes and all its workgroups fit; else, or with SPRINGCRAFT_BULGE_PERSISTENT=0, one launch per wavefront below
+    // ---- persistent chase (k_bulge_chase: one launch, sweeps claimed dynamically) while the stage is latency-bound;
+    // else, or with SPRINGCRAFT_BULGE_PERSISTENT=0, one launch per wavefront below
     static const int env_persist = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PERSISTENT"); return e ? atoi(e) : 1; }();
+    const int persist = ctx->chase_mode >= 0 ? ctx->chase_mode : env_persist;
     bool chased = false;
-    // it pays while the stage is latency-bound (a wavefront's tasks fit the chip about once): measured crossover
-    // batch * n / 128 ~ 1200 (tools/bulge_sweep.py); beyond that the per-wavefront launches on two streams are faster
-    // and, with fewer matrices than XCDs (a matrix is confined to one XCD), only while the order is moderate: a single
-    // n = 12000 matrix chases 1.5 x faster with its ~94 tasks per wavefront spread over the whole chip
-    const bool want_chase = env_persist == 2 ||
-                            (env_persist == 1 && (long long)batch * n / 128 <= 1200 && (batch >= 8 || n <= 6144));
-    // a chase that ran into its time-out once (the GPU is shared, not all workgroups were resident) is not tried again
-    // in this process: every further attempt would cost another time-out before the fallback
-    static std::atomic<int> chase_gave_up{0};
-    if (want_chase && ctx->num_cus > 0 && ctx->num_cus % 8 == 0 && ctx->chase_ok != 0 &&
-        (env_persist == 2 || !chase_gave_up.load())) {
+    // it pays while a wavefront's tasks fit the chip about once: measured crossover batch * n / 128 ~ 1200
+    // (tools/bulge_sweep.py); beyond that the per-wavefront launches on two streams are faster and, with fewer matrices
+    // than XCDs (a matrix is confined to one XCD), only while the order is moderate: a single n = 12000 matrix chases
+    // 1.5 x faster with its ~94 tasks per wavefront spread over the whole chip
+    const bool want_chase =
+        persist == 2 || (persist == 1 && (long long)batch * n / 128 <= 1200 && (batch >= 8 || n <= 6144));
+    // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):
+    // every further attempt could cost another bound's worth of spinning before the fallback
+    if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
-      if (ctx->chase_ok < 0 && per_cu > 0) {   // once per context: does a chip-filling launch give every XCD its share?
-        SC_TRY(sc_reserve_dc_aux(ctx, 256));
-        int* d_counts = reinterpret_cast<int*>(ctx->dc_aux);
-        SC_HIP(ctx, hipMemsetAsync(d_counts, 0, 64, st));
-        void* cargs[] = {&d_counts};
-        int h_counts[9] = {0};
-        bool ok = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_chase_census),
-                                             dim3((unsigned)(per_cu * ctx->num_cus)), dim3(256), cargs, 0, st) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        SC_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, st));
-        SC_HIP(ctx, hipStreamSynchronize(st));
-        for (int x = 0; x < 8; ++x) ok = ok && h_counts[x] == per_cu * ctx->num_cus / 8;
-        ctx->chase_ok = ok ? 1 : 0;
-      }
-      if (ctx->chase_ok != 1) per_cu = 0;
       const int slots_per_xcd = per_cu * ctx->num_cus / 8;
-      const int mpx = (batch + 7) / 8;   // matrices per XCD
+      const int mpx = (batch + 7) / 8;   // matrices per XCD (XCD 0 has the most)
       // workgroups per matrix: all the XCD's slots divided by its matrices, but no more than sweeps can be in flight
       // (every sweep trails its predecessor by two tasks)
       const int useful = std::max(8, chase_len(n, 0) / 2 + 1);
       const int W = slots_per_xcd > 0 ? std::max(1, std::min(useful, slots_per_xcd / mpx)) : 0;
-      const int groups = W > 0 ? std::min(mpx, slots_per_xcd / W) : 0;
-      if (groups >= 1) {
+      if (W >= 1) {
+        // progress counters (batch x n) | claim counters (batch) | ctl
         const size_t prog_bytes = align_up((size_t)batch * n * sizeof(int), 256);
-        SC_TRY(sc_reserve_dc_aux(ctx, prog_bytes + 256));
+        const size_t next_bytes = align_up((size_t)batch * sizeof(int), 256);
+        const size_t ctl_bytes = align_up(kChaseCtlInts * sizeof(int), 256);
+        SC_TRY(sc_reserve_dc_aux(ctx, prog_bytes + next_bytes + ctl_bytes));
         int* d_prog = reinterpret_cast<int*>(ctx->dc_aux);
-        int* d_flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes);
-        SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + 256, st));
-        double* a_sb = d_sb_ws;
-        SbLayout a_sl = SL;
-        static const int env_give_up = [] { const char* e = getenv("SPRINGCRAFT_BULGE_GIVE_UP"); return e ? atoi(e) : 0; }();
-        int a_batch = batch, a_w = W, a_give_up = env_give_up;
-        void* args[] = {&a_sb, &a_sl, &a_batch, &a_w, &d_prog, &d_flags, &a_give_up};
+        int* d_next = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes);
+        int* d_ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes + next_bytes);
+        SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + next_bytes + ctl_bytes, st));
+        // the dispatcher deals workgroups round-robin over the XCDs, so 8 x (workgroups one XCD needs) gives every XCD
+        // its share; the kernel does not rely on it (a short-changed XCD is just slower, see the kernel's header)
+        const int grid = 8 * std::min(slots_per_xcd, mpx * W);
         t_bulge.start();
-        // the whole chip, so that every XCD gets its share of workgroups (roles are drawn per XCD inside the kernel)
-        const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_bulge_chase),
-                                                         dim3((unsigned)(per_cu * ctx->num_cus)), dim3(256), args, 0, st);
+        hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, d_prog, d_next,
+                           d_ctl, ctx->chase_give_up);
+        const hipError_t le = hipGetLastError();
+        t_bulge.stop();
         if (le == hipSuccess) {
-          t_bulge.stop();
-          int h_flags[2] = {0, 0};
-          SC_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+          int h_ctl[kChaseCtlInts] = {0};
+          SC_HIP(ctx, hipMemcpyAsync(h_ctl, d_ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
           SC_HIP(ctx, hipStreamSynchronize(st));
-          if (h_flags[0]) {
-            // A wait ran into its bound (e.g. another process holds part of the GPU, so not all workgroups were
-            // resident).  Workgroups only stop between tasks and every finished task is published, so the counters
-            // describe a consistent state: the per-wavefront launches finish the chase, skipping what is done.
-            ctx->chase_ok = 0;
-            chase_gave_up.store(1);
-            const int t_max2 = 2 * (n - 3) + chase_len(n, n - 3) - 1;
-            for (int t = 0; t <= t_max2; ++t)
-              hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)(chase_len(n, 0) / 2 + 1), (unsigned)batch), dim3(256), 0, st,
-                                 d_sb_ws, SL, t, (const int*)d_prog);
+          long long sweeps = 0;
+          for (int x = 0; x < 8; ++x) {
+            sweeps += h_ctl[16 + x];
+            ctx->chase_tickets[x] = h_ctl[2 + x];
+          }
+          ++ctx->cnt_chase_launches;
+          ctx->cnt_chase_sweeps += sweeps;
+          const bool complete = sweeps == (long long)batch * (n - 2);
+          if (h_ctl[0] || !complete) {
+            // Never expected (see the kernel's header).  A raised flag means a wait ran into its bound (or the test hook
+            // fired); an incomplete chase without a flag means an XCD that owns matrices received no workgroup.  Either
+            // way workgroups only stop between tasks and every finished task is published, so the counters describe a
+            // consistent state: the per-wavefront launches finish the chase, skipping what is done.
+            if (h_ctl[0] && h_ctl[1] == 0) {
+              ++ctx->cnt_chase_timeouts;
+              ctx->chase_ok = 0;
+              ctx->chase_wait[0] = h_ctl[10]; ctx->chase_wait[1] = h_ctl[11]; ctx->chase_wait[2] = h_ctl[12];
+            } else if (!h_ctl[0]) {
+              ++ctx->cnt_chase_incomplete;
+            }
+            ++ctx->cnt_chase_resumed;
+            t_bulge.start();
+            for (int t = 0; t <= t_max; ++t)
+              hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t,
+                                 (const int*)d_prog);
+            t_bulge.stop();
             SC_HIP(ctx, hipGetLastError());
           }
           chased = true;
-        } else {
-          t_bulge.stop();
-          (void)hipGetLastError();   // not launchable here (grid does not fit): the stepwise path takes over
         }
       }
     }
+    if (!chased) ++ctx->cnt_stepwise_chases;
     static const int env_streams = [] { const char* e = getenv("SPRINGCRAFT_BULGE_STREAMS"); return e ? atoi(e) : 0; }();
     // (three parts from 48 matrices on: 477 -> 431 ms at 64; four and more exceed the ~11 us per launch one host thread
     // needs -- the stage then takes 48 k launches x 11.4 us --, and replaying the launches as a captured hipGraph is slower

@@ -195,36 +195,85 @@ def test_batched_ragged_order(sc):
     ctx.close()
 
 
-@pytest.mark.parametrize("give_up", [0, 5, 300])
-def test_persistent_chase_and_resume(give_up):
-    """
-    The persistent bulge chase (forced), alone and giving up after `give_up` tasks per workgroup: the per-wavefront
-    launches then finish the chase from the published progress counters.  Own process: the library reads the switches once.
-    """
-    import os
-    import subprocess
-    import sys
+def _lib_dbg():
+    import ctypes as C
 
-    code = r'''
-import numpy as np
-import springcraft_amd as sc
-from springcraft_amd import _hip
-rs = np.random.RandomState(7)
-for n, batch in ((1030, 1), (520, 3)):
-    mats = []
-    for b in range(batch):
-        a = rs.standard_normal((n, n)); mats.append(0.5 * (a + a.T))
-    ctx = _hip.context()
-    ctx.set_two_stage(True)
-    for a in mats:
-        w, v = sc.nma.eigh(a)
-        w_ref = np.linalg.eigvalsh(a)
-        assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max(), np.abs(w - w_ref).max()
-        assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-10 * np.abs(w_ref).max()
-        assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-11
-print("ok")
-'''
-    env = dict(os.environ, SPRINGCRAFT_BULGE_PERSISTENT="2", SPRINGCRAFT_BULGE_GIVE_UP=str(give_up))
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+    from springcraft_amd import _hip
+
+    L = _hip.lib()
+    L.sc_dbg_set_chase.restype = C.c_int
+    L.sc_dbg_set_chase.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    return L
+
+
+@pytest.mark.parametrize("n,batch", [(1200, 8), (1030, 32), (1030, 1), (520, 3)])
+@pytest.mark.parametrize("give_up", [0, 5, 100])
+def test_persistent_chase_and_resume(n, batch, give_up):
+    """
+    The persistent bulge chase (forced on through the debug entry) as ONE batched solve -- several matrices per XCD at
+    batch 32, one XCD without a matrix at batch 3 -- and the event counters of the context: without the test hook the
+    chase must finish every sweep itself (no time-out, no take-over by the per-wavefront launches); with the hook
+    (every workgroup raises the flag after `give_up` tasks) the take-over must have run, and the eigenpairs are the
+    same either way.
+    """
+    import ctypes as C
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    L = _lib_dbg()
+    rs = np.random.RandomState(7 + n + batch)
+    mats = np.stack([sym(rs, n) for _ in range(batch)])
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_two_stage(True)
+        ctx.check(L.sc_dbg_set_chase(ctx.handle, 2, give_up))
+        a = torch.from_numpy(mats.copy()).cuda()
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(v.data_ptr())))
+        ctx.synchronize()
+        cnt = {k: ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_incomplete", "chase_resumed",
+                                           "chase_sweeps", "stepwise_chases", "chase_xcd_min", "chase_xcd_max")}
+        assert cnt["chase_launches"] == 1 and cnt["stepwise_chases"] == 0, cnt
+        assert cnt["chase_timeouts"] == 0 and cnt["chase_incomplete"] == 0, cnt
+        if give_up == 0:
+            assert cnt["chase_resumed"] == 0 and cnt["chase_sweeps"] == batch * (n - 2), cnt
+        else:
+            assert cnt["chase_resumed"] == 1 and cnt["chase_sweeps"] < batch * (n - 2), cnt
+        # every matrix: residual and orthogonality on the device; eigenvalues of the first and last against LAPACK
+        am = torch.from_numpy(mats).cuda()
+        eye = torch.eye(n, dtype=torch.float64, device="cuda")
+        for b in range(batch):
+            r = am[b] @ v[b].T - v[b].T * w[b][None, :]
+            assert float(r.abs().max()) <= 1e-10 * float(w[b].abs().max()), (b, cnt)
+            assert float((v[b] @ v[b].T - eye).abs().max()) <= 1e-11, (b, cnt)
+        for b in sorted({0, batch - 1}):
+            w_ref = np.linalg.eigvalsh(mats[b])
+            assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.close()
+
+
+def test_chase_by_size_rule_counts(sc):
+    """The automatic rule: a latency-bound batch takes the persistent chase, and the counters say it completed."""
+    import os
+
+    import torch
+
+    from springcraft_amd.batch import DeviceBatchSolver
+
+    if os.environ.get("SPRINGCRAFT_BULGE_PERSISTENT") is not None:
+        pytest.skip("the size rule is overridden (tools/test_matrix.sh)")
+    n_atoms, B = 400, 8
+    coords = torch.from_numpy(np.stack([synthetic_coord(n_atoms, s) for s in range(B)])).cuda()
+    s = DeviceBatchSolver(n_atoms, B, sc.InvariantForceField(13.0))
+    s.ctx.set_two_stage(True)
+    for _ in range(3):
+        s.solve(coords)
+    torch.cuda.synchronize()
+    assert s.ctx.counter("chase_launches") == 3 and s.ctx.counter("chase_sweeps") == 3 * B * (3 * n_atoms - 2)
+    assert s.ctx.counter("chase_timeouts") == 0 and s.ctx.counter("chase_resumed") == 0
+    assert s.ctx.counter("chase_xcd_min") >= 1
