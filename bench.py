@@ -3,18 +3,19 @@
 bench.py — headline benchmark of BASELINE.json: ANM modes/s (Hessian build + full eigensolve),
 N = 2000 C-alpha, HinsenForceField without cutoff (config C3), float64, all 6000 modes.
 
-    python bench.py --gpus N --steps K --warmup W [--config c3|c4] [--structures-per-gpu B] [--n-atoms 2000]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--structures-per-gpu B] [--n-atoms N]
 
 With ``--gpus N`` (N > 1) and no RANK in the environment the script starts the N ranks itself (a child
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...``, started
 before this process makes any GPU call) and exits with the child's code; under torchrun it reads
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  WORLD_SIZE != --gpus is an error.
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  WORLD_SIZE != --gpus is an error.  With more than one
+rank every rank pins its host threads to the cores of its GPU's NUMA node before its first GPU call.
 
---config c3 (default, the metric's configuration)
-    One "step" = one pass of the hot path over one batch of B synthetic structures per GPU whose coordinates are
-    already resident in HBM: batched Hessian assembly (HIP) -> batched eigensolve (HIP), eigenvalues and eigenvectors
-    left resident in HBM.  Structures are independent, so ranks share no data-path collective (weak scaling: B
-    structures per GPU); RCCL is only used for the barrier and the max-over-ranks of the elapsed time.
+--config c3 (default, the metric's configuration), c2 (N = 512, InvariantForceField 13 A), c5 (N = 8000, modes 0..105)
+    One "step" = one pass of the hot path over one batch of B synthetic structures per GPU (c2 / c3: 64, c5: 1) whose
+    coordinates are already resident in HBM: batched Hessian assembly (HIP) -> batched eigensolve (HIP), eigenvalues and
+    eigenvectors left resident in HBM.  Structures are independent, so ranks share no data-path collective (weak
+    scaling: B structures per GPU); RCCL is only used for the barrier and the max-over-ranks of the elapsed time.
 --config c4 (BASELINE.json configs[3])
     32 * N independent N = 1000 C-alpha ANM solves (InvariantForceField 13 A) through
     ``springcraft_amd.batch.solve_sharded``: the root scatters the coordinate shards over RCCL, every rank solves its
@@ -22,17 +23,20 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  WORLD_SIZE != -
     timed region); eigenvalues of every structure are checked against the oracle-independent residual on the ranks.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel of the path taken (two-stage: k_bt2_apply, f64-MFMA bound: algorithmic flops of the
-                launch / its duration vs the 78.6 TFLOP/s f64 matrix peak; one-stage: k_symv_tiles, HBM bound).
-                Durations from HIP events on the solver's stream in one extra profiled step right after the timed
-                region.  ``traffic`` only from a PMC pass collected at the benchmarked (n, batch), else null.
-  rooflines     the other two rooflines BASELINE.json's north star names: ``assembly`` (k_hessian: 72 B per ordered
-                atom pair / kernel time vs 8 TB/s HBM) and ``band_reduction`` / ``syr2k`` (f64-MFMA fraction), plus
-                ``bulge_chasing`` (k_bulge_step: algorithmic bytes of the chase / wall time of the stage vs 8 TB/s)
+  roofline      the kernel (group) with the longest duration in one extra profiled step right after the timed region
+                (C3: k_bt2_apply, f64-MFMA bound: algorithmic flops of the launch / its duration vs the 78.6 TFLOP/s
+                f64 matrix peak; one-stage path: k_symv_tiles, HBM bound).  Durations from HIP events on the solver's
+                stream.  ``traffic`` only from a PMC pass collected at the benchmarked (n, batch), else null.
+  rooflines     every kernel group with a model: ``assembly`` (k_hessian: 72 B per ordered atom pair / kernel time vs
+                8 TB/s HBM), ``band_reduction`` / ``syr2k`` / ``symm`` / ``bt2_apply`` / ``bt1_*`` (f64-MFMA fraction),
+                ``bulge_chasing`` (bytes the implementation moves AND the compulsory bytes / wall time vs 8 TB/s)
+  counters      persistent-chase event counters of the solver's context (sc_ctx_get_counter): time-outs must be 0
   parity_gates  SURVEY.md section 8(d): contact counts, pair list, Kirchhoff (bit exact), Hessian (rel. Frobenius),
                 eigenvalues vs the CPU run, residual and orthogonality of several structures of the timed batch
+                (c5: reference-generated eigenvalues, residual of all 106 vectors, analytic rigid-body null space)
   cpu_baseline  the oracle (NumPy restatement of compute_hessian + numpy.linalg.eigh = LAPACK dsyevd, the
-                reference's own driver) on this box's host cores, median of 3 runs of ONE structure
+                reference's own driver) on this box's host cores, median over a bounded sample of ONE-structure runs
+                (c5: scipy.linalg.eigh(subset_by_index) on a smaller structure, scaled by N^3 and said so)
 """
 import argparse
 import json
@@ -116,21 +120,28 @@ def synthetic_coords(n_atoms, seeds):
     return out
 
 
-def cpu_baseline(n_atoms, ff_name, runs=3):
-    """Oracle on the host cores: one structure of the same workload, median of `runs` (bounded sample)."""
-    from oracle import enm_oracle as orc
-
+def host_threads():
     try:
         from threadpoolctl import threadpool_info
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
     except Exception:
-        cores = os.cpu_count() or 1
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(n_atoms, ff_name, runs=3, budget_s=12.0):
+    """
+    Oracle on the host cores: ONE structure of the same workload per run, at least `runs` runs and as many more as fit
+    into `budget_s` seconds (bounded sample); the reported figure is the median run.
+    """
+    from oracle import enm_oracle as orc
+
     coord = synthetic_coords(n_atoms, [0])[0]
     ff = orc.hinsen_ff() if ff_name == "hinsen" else orc.invariant_ff(13.0)
     ta, te = [], []
     h = pairs = w = None
-    for _ in range(runs):
+    t_begin = time.perf_counter()
+    while len(ta) < runs or (time.perf_counter() - t_begin < budget_s and len(ta) < 64):
         t0 = time.perf_counter()
         h, pairs = orc.compute_hessian(coord, ff)
         t1 = time.perf_counter()
@@ -140,18 +151,54 @@ def cpu_baseline(n_atoms, ff_name, runs=3):
         te.append(t2 - t1)
     tot = sorted(a + e for a, e in zip(ta, te))
     med = tot[len(tot) // 2]
+    shown = ", ".join(f"{t:.2f}" for t in tot[:8]) + (" ..." if len(tot) > 8 else "")
     return {
         "value": 3 * n_atoms / med,
         "unit": "modes/s",
-        "cores": int(cores),
+        "cores": host_threads(),
         "kind": "port",
-        "sample": (f"1 structure N={n_atoms}, median of {runs} runs: assembly {sorted(ta)[len(ta) // 2]:.2f} s + "
-                   f"numpy.linalg.eigh {sorted(te)[len(te) // 2]:.2f} s (runs: " + ", ".join(f"{t:.2f}" for t in tot) + " s)"),
+        "sample": (f"1 structure N={n_atoms}, median of {len(tot)} runs: assembly {sorted(ta)[len(ta) // 2]:.2f} s + "
+                   f"numpy.linalg.eigh {sorted(te)[len(te) // 2]:.2f} s (runs: {shown} s)"),
     }, h, pairs, w
 
 
+def cpu_baseline_partial(n_atoms, n_modes, sample_atoms=3000):
+    """
+    Config C5 on the host: the reference itself has no partial-spectrum mode (nma.py:61 always solves for all n), so
+    the baseline is the oracle's Hessian + scipy.linalg.eigh(subset_by_index) (LAPACK dsyevr), what a user of the
+    reference would write.  One N = 8000 solve takes minutes on the host; the bounded sample is ONE solve at
+    N = sample_atoms (same density, same force field), scaled by (N / sample_atoms)^3 -- tridiagonalisation dominates
+    and is cubic -- and said so in `sample`.
+    """
+    from oracle import enm_oracle as orc
+
+    coord = synthetic_coords(sample_atoms, [0])[0]
+    t0 = time.perf_counter()
+    h, _ = orc.compute_hessian(coord, orc.invariant_ff(13.0))
+    t1 = time.perf_counter()
+    try:
+        import scipy.linalg
+
+        scipy.linalg.eigh(h, subset_by_index=[0, n_modes - 1], overwrite_a=True, check_finite=False)
+        how = "scipy.linalg.eigh(subset_by_index)"
+    except ImportError:
+        np.linalg.eigh(h)
+        how = "numpy.linalg.eigh (all modes; scipy missing)"
+    t2 = time.perf_counter()
+    scale = (n_atoms / sample_atoms) ** 3
+    est = (t2 - t0) * scale
+    return {
+        "value": n_modes / est, "unit": "modes/s", "cores": host_threads(), "kind": "port",
+        "sample": (f"ONE solve at N={sample_atoms} (assembly {t1 - t0:.2f} s + {how} {t2 - t1:.2f} s), scaled by "
+                   f"(N/{sample_atoms})^3 = {scale:.1f} to N={n_atoms}: estimated {est:.0f} s per solve"),
+    }
+
+
 def spawn_ranks(args):
-    """--gpus N without a rank environment: start the N ranks as a child job (nothing here has touched the GPU)."""
+    """
+    --gpus N without a rank environment: start the N ranks as a child job (nothing here has touched the GPU).  Every rank
+    binds itself to the host cores next to its GPU before its first GPU call (bind_rank_to_numa_node).
+    """
     import socket
 
     with socket.socket() as s:
@@ -164,7 +211,47 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def parity_gates(sc, solver, coord, w_all, v_all, n_atoms, cpu_h, cpu_pairs, cpu_w, torch):
+def bind_rank_to_numa_node(local_rank):
+    """
+    One process per GPU: keep the rank's host threads (the launch thread issues ~50 k kernel launches per step) on the
+    cores of the NUMA node its GPU hangs off, read from sysfs (no GPU call).  Best effort: anything missing -> no binding.
+    Returns a short description for the bench line.
+    """
+    try:
+        import glob
+
+        # the render nodes' PCI devices in bus order = HIP's default device order on a single-node box
+        devs = []
+        for d in sorted(glob.glob("/sys/class/drm/renderD*/device")):
+            try:
+                with open(os.path.join(d, "vendor")) as f:
+                    if f.read().strip() != "0x1002":
+                        continue
+                devs.append(os.path.realpath(d))
+            except OSError:
+                continue
+        devs.sort()
+        if local_rank >= len(devs):
+            return "unbound (GPU not found in sysfs)"
+        with open(os.path.join(devs[local_rank], "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return "unbound (no NUMA information)"
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return f"unbound (NUMA node {node} outside the allowed CPU set)"
+        os.sched_setaffinity(0, allowed)
+        return f"NUMA node {node}, {len(allowed)} cpus"
+    except Exception as e:   # noqa: BLE001
+        return f"unbound ({type(e).__name__})"
+
+
+def parity_gates(sc, solver, coord, w_all, v_all, n_atoms, ff_name, cpu_h, cpu_pairs, cpu_w, torch):
     """SURVEY.md section 8(d) gates on the batch that was just timed (device results vs the oracle's structure 0)."""
     from oracle import enm_oracle as orc
 
@@ -177,7 +264,7 @@ def parity_gates(sc, solver, coord, w_all, v_all, n_atoms, cpu_h, cpu_pairs, cpu
     gates["contact_counts_inv13_equal"] = bool(np.array_equal(np.diag(k_gpu).astype(np.int64), np.diag(k_cpu).astype(np.int64)))
     gates["pairs_inv13_equal"] = bool(np.array_equal(p_gpu, p_cpu))
     # the benchmarked force field: pair list and Hessian of structure 0
-    h_gpu, p_gpu = sc.compute_hessian(c0, sc.HinsenForceField())
+    h_gpu, p_gpu = sc.compute_hessian(c0, sc.HinsenForceField() if ff_name == "hinsen" else sc.InvariantForceField(13.0))
     gates["pairs_equal"] = bool(np.array_equal(p_gpu, cpu_pairs))
     gates["n_pairs"] = int(len(p_gpu))
     gates["hessian_rel_frobenius"] = float(np.linalg.norm(h_gpu - cpu_h) / np.linalg.norm(cpu_h))
@@ -210,15 +297,172 @@ def parity_gates(sc, solver, coord, w_all, v_all, n_atoms, cpu_h, cpu_pairs, cpu
     return gates
 
 
-def run_c3(args, rank, world, torch, dist):
+def parity_gates_partial(solver, coord, w, v, torch):
+    """
+    Config C5 gates: eigenvalues against the reference-generated vector (tests/golden/generated/c5_n8000_inv13.npz, made
+    by importing the reference in the build container), residual of every returned vector with the Hessian applied on
+    the device, orthonormality, and the six trivial modes against the analytic rigid-body null space.
+    """
+    gates = {}
+    n_atoms = coord.shape[1]
+    n = 3 * n_atoms
+    wd, vd = w[0], v[0]
+    w_np, v_np = wd.cpu().numpy(), vd.cpu().numpy()
+    ref_file = os.path.join(ROOT, "tests", "golden", "generated", "c5_n8000_inv13.npz")
+    if n_atoms == 8000 and os.path.exists(ref_file):
+        ref = np.load(ref_file)["eigenvalues_low106"][: len(w_np)]
+        gates["eigenvalues_max_rel_diff_nontrivial"] = float((np.abs(w_np[6:] - ref[6:]) / np.abs(ref[6:])).max())
+    h = solver.assemble(coord)[0]
+    x = torch.ones(n, dtype=torch.float64, device=h.device)
+    for _ in range(30):           # power iteration: ||H||_2 from below
+        x = h @ x
+        x = x / torch.linalg.vector_norm(x)
+    lam_max = float(x @ (h @ x))
+    r = h @ vd.T - vd.T * wd[None, :]
+    gates["residual_max_over_norm"] = float(torch.linalg.vector_norm(r, dim=0).max() / lam_max)
+    gates["orthogonality_max"] = float((vd @ vd.T - torch.eye(len(w_np), dtype=torch.float64, device=h.device)).abs().max())
+    gates["trivial_modes_max_abs_over_lambda_max"] = float(np.abs(w_np[:6]).max() / lam_max)
+    c = coord[0].cpu().numpy()
+    basis = np.zeros((n, 6))
+    for a in range(3):
+        basis[a::3, a] = 1.0
+        e = np.zeros(3)
+        e[a] = 1.0
+        basis[:, 3 + a] = np.cross(e[None, :], c - c.mean(0)).reshape(-1)
+    q, _ = np.linalg.qr(basis)
+    sv = np.linalg.svd(q.T @ v_np[:6].T, compute_uv=False)
+    gates["null_space_singular_values_max_dev"] = float(np.abs(sv - 1.0).max())
+    gates["other_modes_max_overlap_with_null_space"] = float(np.abs(q.T @ v_np[6:].T).max())
+    gates["pass"] = bool(gates.get("eigenvalues_max_rel_diff_nontrivial", 0.0) <= 1e-5
+                         and gates["residual_max_over_norm"] <= 1e-5 and gates["orthogonality_max"] <= 1e-8
+                         and gates["trivial_modes_max_abs_over_lambda_max"] <= 1e-9
+                         and gates["null_space_singular_values_max_dev"] <= 1e-6
+                         and gates["other_modes_max_overlap_with_null_space"] <= 1e-6)
+    return gates
+
+
+def bulge_compulsory_bytes(n):
+    """What band -> tridiagonal must move per matrix whatever the schedule: the band in (65 x n) and the reflectors out."""
+    s = np.arange(0, n - 2, dtype=np.int64)
+    refl = 0
+    for k in range((n - 1 + 63) // 64):
+        refl += int(np.clip(n - (s + 1 + 64 * k), 0, 64).sum())
+    return 8 * (65 * n + refl)
+
+
+def build_rooflines(t, n, B, ncols):
+    """
+    (dominant-kernel roofline, all rooflines) from the phase durations `t` of one profiled step.  n: matrix order,
+    B: matrices per launch, ncols: eigenvector columns the back-transformations are applied to.
+    Algorithmic work per matrix: SYMM X = A22 V and the trailing SYR2K 2/3 n^3 flops each; k_bt2_apply 4 L
+    flops per reflector of length L and column; stage-1 back-transformation n^2 ncols per GEMM (W = V^T Z; Z -= (V T) W);
+    bulge chasing see bulge_bytes / bulge_compulsory_bytes; one-stage SYMV 8 B per lower-triangle element and column.
+    """
+    cand = {}
+
+    def mfma(name, kernel, flops, ms, what, extra=None):
+        if not ms or ms <= 0:
+            return
+        a = flops / (ms * 1e-3) / 1e12
+        cand[name] = {"kernel": kernel, "bound": "mfma", "achieved": round(a, 2), "peak": F64_MFMA_PEAK_TF,
+                      "unit": "TFLOP/s", "frac": round(a / F64_MFMA_PEAK_TF, 4), "ms": round(ms, 3), "what": what}
+        if extra:
+            cand[name].update(extra)
+
+    n3 = float(n) ** 3
+    if t.get("two_stage"):
+        alg, executed = bt2_flops(n, ncols)
+        mfma("bt2_apply", "k_bt2_apply", alg * B, t.get("bt2_apply_ms"),
+             "stage-2 back-transformation: 4 L flops per reflector and eigenvector column / duration of the ONE launch",
+             {"launches_per_step": 1, "algorithmic_flops_per_launch": alg * B, "executed_flops_per_launch": executed * B,
+              "executed_over_algorithmic": round(executed / alg, 4) if alg else None,
+              "executed_tflops": round(executed * B / (t["bt2_apply_ms"] * 1e-3) / 1e12, 2) if t.get("bt2_apply_ms") else None,
+              "traffic": pmc_traffic("bt2", n, B) if ncols == n else None})
+        mfma("band_reduction", "stage 1 (panel QR + SYMM + Gram + W + SYR2K)", 4.0 / 3.0 * n3 * B, t.get("band_reduction_ms"),
+             "4/3 n^3 flops per matrix / duration of the whole stage incl. the panel QRs")
+        mfma("syr2k", "k_gemm2 (trailing SYR2K launches)", 2.0 / 3.0 * n3 * B, t.get("syr2k_ms"),
+             "trailing SYR2K launches of the band reduction alone: 2/3 n^3 flops per matrix / their duration")
+        mfma("symm", "k_gemm2 (triangular-operand X = A22 V launches)", 2.0 / 3.0 * n3 * B, t.get("symm_ms"),
+             "X = A22 V on the lower-stored A22: 2/3 n^3 flops per matrix / duration of those launches")
+        mfma("bt1_w", "k_gemm2 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"),
+             "stage-1 back-transformation, first product: n^2 ncols flops per matrix")
+        mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
+             "stage-1 back-transformation, second product: n^2 ncols flops per matrix")
+        if t.get("bulge_chasing_ms", 0) > 0:
+            bb = bulge_bytes(n) * B
+            cb = bulge_compulsory_bytes(n) * B
+            ms = t["bulge_chasing_ms"]
+            bw = bb / (ms * 1e-3) / 1e9
+            cand["bulge_chasing"] = {
+                "kernel": "k_bulge_step / k_bulge_chase", "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(bw / HBM_PEAK_GBS, 4), "ms": round(ms, 3),
+                "executed_bytes_per_step": bb, "compulsory_bytes_per_step": cb,
+                "compulsory_frac": round(cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "executed_over_compulsory": round(bb / cb, 1),
+                "what": "stage 2 (band -> tridiagonal).  `achieved` counts what the implementation moves (every task reads "
+                        "and writes its off-diagonal block and the lower triangle of its diagonal block); "
+                        "`compulsory_*` counts only the band in + the reflectors out, the bytes any schedule must move.  "
+                        "Wall time of the stage (HIP events; parts of the batch run on separate streams, so per-kernel "
+                        "durations in a rocprof summary overlap and add up to more)",
+            }
+    else:
+        launches = max(n - 2, 1)
+        if t.get("symv_ms", 0) > 0:
+            bytes_per_launch = symv_algorithmic_bytes(n) * B / launches   # batched launch: B matrices
+            avg_ms = t["symv_ms"] / launches
+            a = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            cand["symv"] = {
+                "kernel": "k_symv_tiles", "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(t["symv_ms"], 3),
+                "traffic": pmc_traffic("symv", n, B), "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
+                "what": "one-stage tridiagonalisation: y = A22 v, 8 B per lower-triangle element per column",
+            }
+        mfma("syr2k", "k_gemm2 (SYR2K)", 2.0 / 3.0 * n3 * B, t.get("syr2k_ms"), "panel SYR2K launches: 2/3 n^3 flops per matrix")
+        mfma("bt1_w", "k_gemm2 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"), "back-transformation, first product")
+        mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
+             "back-transformation, second product")
+    # dominant = the single kernel (group) with the longest duration; the band reduction as a whole is a stage, not a kernel
+    kernels = {k: v for k, v in cand.items() if k != "band_reduction"}
+    if not kernels:
+        return None, cand
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    roofline = dict(kernels[dom])
+    roofline["name"] = dom
+    roofline.setdefault("traffic", None)
+    roofline["avg_launch_ms"] = roofline.get("avg_launch_ms", roofline["ms"] / roofline.get("launches_per_step", 1))
+    roofline["measured"] = "HIP events on the solver's stream around the kernel (group), one extra profiled step after the timed region"
+    return roofline, cand
+
+
+BATCH_CONFIGS = {
+    # name: (n_atoms, force field, structures per GPU per step, subset, metric, workload text)
+    "c2": (512, "inv13", 64, None, "ANM modes/sec (Hessian build + full eigensolve), N=512 C-alpha (config C2)",
+           "C2: N={n_atoms} C-alpha ANM, InvariantForceField 13 A, full {n}x{n} eigensolve, all modes + vectors"),
+    "c3": (2000, "hinsen", 64, None, "ANM modes/sec (Hessian build + full eigensolve), N=2000 C-alpha",
+           "C3: N={n_atoms} C-alpha ANM, HinsenForceField (no cutoff), full {n}x{n} eigensolve, all modes + vectors"),
+    "c5": (8000, "inv13", 1, (0, 105), "ANM modes/sec, N=8000 C-alpha, lowest 106 modes only (config C5, partial spectrum)",
+           "C5: N={n_atoms} C-alpha ANM, InvariantForceField 13 A, {n}x{n} Hessian, modes 0..105 (6 trivial + 100) + vectors"),
+}
+
+
+def run_batch(args, rank, world, torch, dist):
+    """Configs c2 / c3 / c5: B structures per GPU per step, coordinates resident in HBM, no data-path collective."""
     import springcraft_amd as sc
     from springcraft_amd.batch import DeviceBatchSolver
 
-    n_atoms, B = args.n_atoms, args.structures_per_gpu
+    n_atoms_d, ff_name, B_d, subset, metric, workload = BATCH_CONFIGS[args.config]
+    n_atoms = args.n_atoms if args.n_atoms else n_atoms_d
+    B = args.structures_per_gpu if args.structures_per_gpu_set else B_d
     n = 3 * n_atoms
     seeds = [rank * B + k for k in range(B)]
-    coord = torch.from_numpy(synthetic_coords(n_atoms, seeds)).cuda()
-    solver = DeviceBatchSolver(n_atoms, B, sc.HinsenForceField(), dim=3, want_vectors=True)
+    box = 100.0 if (args.config == "c5" and n_atoms == 8000) else None
+    coords_np = synthetic_coords(n_atoms, seeds) if box is None else np.stack(
+        [np.random.RandomState(s).rand(n_atoms, 3) * box for s in seeds])
+    coord = torch.from_numpy(coords_np).cuda()
+    ff = sc.HinsenForceField() if ff_name == "hinsen" else sc.InvariantForceField(13.0)
+    solver = DeviceBatchSolver(n_atoms, B, ff, dim=3, want_vectors=True, subset_by_index=subset)
+    nmodes = n if subset is None else subset[1] - subset[0] + 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -241,67 +485,13 @@ def run_c3(args, rank, world, torch, dist):
 
     out = None
     if rank == 0:
-        # ---- one extra profiled step: durations of the dominant kernel and of the phases (HIP events, solver's stream)
+        # ---- one extra profiled step: durations of the kernel groups (HIP events, solver's stream)
         solver.set_profiling(True)
         w, v = solver.solve(coord)
         torch.cuda.synchronize()
         t = solver.last_timings()
         solver.set_profiling(False)
-        phases = dict(t)
-        rooflines = {}
-        if t.get("two_stage"):
-            alg, executed = bt2_flops(n, n)
-            ms = t["bt2_apply_ms"]
-            achieved = alg * B / (ms * 1e-3) / 1e12
-            roofline = {
-                "kernel": "k_bt2_apply", "bound": "mfma", "achieved": round(achieved, 2), "peak": F64_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TF, 4), "traffic": pmc_traffic("bt2", n, B),
-                "launches_per_step": 1, "algorithmic_flops_per_launch": alg * B,
-                "executed_flops_per_launch": executed * B,
-                "executed_tflops": round(executed * B / (ms * 1e-3) / 1e12, 2), "avg_launch_ms": round(ms, 3),
-                "measured": "HIP events around the launch, one extra profiled step after the timed region",
-            }
-            # stage 1 (band reduction): 4/3 n^3 flops per matrix, all of them MFMA GEMMs (SYMM, W, SYR2K) + panel QR
-            br = 4.0 / 3.0 * float(n) ** 3 * B / (t["band_reduction_ms"] * 1e-3) / 1e12
-            rooflines["band_reduction"] = {
-                "bound": "mfma", "achieved": round(br, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(br / F64_MFMA_PEAK_TF, 4),
-                "what": "4/3 n^3 flops per matrix / duration of the whole stage incl. the panel QRs",
-            }
-            if t.get("syr2k_ms", 0) > 0:
-                sy = 2.0 / 3.0 * float(n) ** 3 * B / (t["syr2k_ms"] * 1e-3) / 1e12
-                rooflines["syr2k"] = {
-                    "bound": "mfma", "achieved": round(sy, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(sy / F64_MFMA_PEAK_TF, 4),
-                    "what": "trailing SYR2K launches of the band reduction alone: 2/3 n^3 flops per matrix / their duration",
-                }
-            if t.get("bulge_chasing_ms", 0) > 0:
-                bb = bulge_bytes(n) * B
-                bw = bb / (t["bulge_chasing_ms"] * 1e-3) / 1e9
-                rooflines["bulge_chasing"] = {
-                    "kernel": "k_bulge_step", "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(bw / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": bb,
-                    "what": "stage 2 (band -> tridiagonal): every task reads and writes its off-diagonal block and the lower "
-                            "triangle of its diagonal block / wall time of the stage (HIP events; its launches run as "
-                            "parts of the batch on separate streams, so per-kernel durations in a rocprof summary overlap "
-                            "and add up to more than this)",
-                }
-        else:
-            launches = (n - 2)
-            bytes_per_launch = symv_algorithmic_bytes(n) * B / launches   # batched launch: B matrices
-            avg_ms = t["symv_ms"] / launches
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {
-                "kernel": "k_symv_tiles", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("symv", n, B),
-                "launches_per_step": launches, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                "avg_launch_ms": round(avg_ms, 5),
-                "measured": "HIP events around every launch, one extra profiled step after the timed region",
-            }
-            if t["syr2k_ms"] > 0:
-                sy = 2.0 / 3.0 * float(n) ** 3 * B / (t["syr2k_ms"] * 1e-3) / 1e12
-                rooflines["syr2k"] = {"bound": "mfma", "achieved": round(sy, 2), "peak": F64_MFMA_PEAK_TF,
-                                      "unit": "TFLOP/s", "frac": round(sy / F64_MFMA_PEAK_TF, 4)}
+        roofline, rooflines = build_rooflines(t, n, B, nmodes)
         # ---- assembly roofline: k_hessian alone (one launch per assemble), events on the same stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
@@ -320,25 +510,31 @@ def run_c3(args, rank, world, torch, dist):
             "algorithmic_bytes_per_launch": round(asm_bytes),
             "what": "72 B per ordered atom pair (9 N^2 f64 written once) + 24 N B read, per structure",
         }
+        counters = {k: solver.ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")}
 
         total_structures = B * world * args.steps
-        value = 3 * n_atoms * total_structures / elapsed
+        value = nmodes * total_structures / elapsed
         cpu = gates = None
         if not args.no_cpu_baseline:
-            cpu, cpu_h, cpu_pairs, cpu_w = cpu_baseline(n_atoms, "hinsen", runs=args.cpu_runs)
-            gates = parity_gates(sc, solver, coord, w, v, n_atoms, cpu_h, cpu_pairs, cpu_w, torch)
+            if subset is None:
+                cpu, cpu_h, cpu_pairs, cpu_w = cpu_baseline(n_atoms, ff_name, runs=args.cpu_runs)
+                gates = parity_gates(sc, solver, coord, w, v, n_atoms, ff_name, cpu_h, cpu_pairs, cpu_w, torch)
+            else:
+                gates = parity_gates_partial(solver, coord, w.clone(), v.clone(), torch)
+                cpu = cpu_baseline_partial(n_atoms, nmodes)
         out = {
-            "metric": "ANM modes/sec (Hessian build + full eigensolve), N=2000 C-alpha",
+            "metric": metric,
             "value": round(value, 1), "unit": "modes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"C3: N={n_atoms} C-alpha ANM, HinsenForceField (no cutoff), full {n}x{n} eigensolve, all modes + vectors",
+                "workload": workload.format(n_atoms=n_atoms, n=n),
                 "structures_per_gpu_per_step": B,
                 "solves_per_s": round(total_structures / elapsed, 3),
                 "parallelism": "independent structures sharded over GPUs, no data-path collective",
+                "host_binding": args.host_binding,
             },
-            "roofline": roofline, "rooflines": rooflines, "phases_ms_profiled_step": phases,
+            "roofline": roofline, "rooflines": rooflines, "phases_ms_profiled_step": dict(t), "counters": counters,
             "parity_gates": gates, "cpu_baseline": cpu,
         }
     return out
@@ -350,6 +546,7 @@ def run_c4(args, rank, world, torch, dist):
     from springcraft_amd.batch import DeviceBatchSolver, shard_bounds, solve_sharded
 
     n_atoms, per_gpu = 1000, args.structures_per_gpu if args.structures_per_gpu_set else 32
+    n = 3 * n_atoms
     total = per_gpu * world
     ff = sc.InvariantForceField(13.0)
     coords = synthetic_coords(n_atoms, list(range(total))) if rank == 0 else None
@@ -374,13 +571,15 @@ def run_c4(args, rank, world, torch, dist):
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    # every rank checks its own shard: residual + orthogonality of its first and last structure (device arithmetic)
-    h_all = solver.assemble(solver.last_coord)
+    # every rank checks its own shard: residual + orthogonality of its first and last structure (device arithmetic);
+    # the shard's coordinates are regenerated from the seeds (the scatter's own correctness is what w is checked for below)
+    local = torch.from_numpy(synthetic_coords(n_atoms, list(range(lo, hi)))).cuda()
+    w_keep, v_keep = solver.w.clone(), [solver.v[b].clone() for b in sorted(set([0, hi - lo - 1]))]
+    h_all = solver.assemble(local)
     worst = torch.zeros(2, dtype=torch.float64, device="cuda")
-    
-    eye = torch.eye(3 * n_atoms, dtype=torch.float64, device="cuda")
-    for b in sorted(set([0, hi - lo - 1])):
-        hb, wb, vb = h_all[b], solver.w[b], solver.v[b]
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    for j, b in enumerate(sorted(set([0, hi - lo - 1]))):
+        hb, wb, vb = h_all[b], w_keep[b], v_keep[j]
         r = hb @ vb.T - vb.T * wb[None, :]
         worst[0] = max(worst[0], torch.linalg.vector_norm(r, dim=0).max() / wb.abs().max())
         worst[1] = max(worst[1], (vb @ vb.T - eye).abs().max())
@@ -388,6 +587,14 @@ def run_c4(args, rank, world, torch, dist):
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     out = None
     if rank == 0:
+        # one extra profiled local solve of rank 0's shard: kernel-group durations -> rooflines
+        solver.set_profiling(True)
+        solver.solve(local)
+        torch.cuda.synchronize()
+        tt = solver.last_timings()
+        solver.set_profiling(False)
+        roofline, rooflines = build_rooflines(tt, n, hi - lo, n)
+        counters = {k: solver.ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")}
         cpu = gates = None
         if not args.no_cpu_baseline:
             from oracle import enm_oracle as orc
@@ -420,8 +627,10 @@ def run_c4(args, rank, world, torch, dist):
                 "solves_per_s": round(total * args.steps / elapsed, 3),
                 "parallelism": "independent structures sharded over GPUs; collectives only for scatter / gather",
                 "backend": dist.get_backend(),
+                "host_binding": args.host_binding,
             },
-            "roofline": None, "parity_gates": gates, "cpu_baseline": cpu,
+            "roofline": roofline, "rooflines": rooflines, "phases_ms_profiled_step": dict(tt), "counters": counters,
+            "parity_gates": gates, "cpu_baseline": cpu,
         }
     return out
 
@@ -431,15 +640,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["c3", "c4"], default="c3")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3")
     ap.add_argument("--structures-per-gpu", type=int, default=None)
-    ap.add_argument("--n-atoms", type=int, default=2000)
+    ap.add_argument("--n-atoms", type=int, default=0, help="override the configuration's atom count (c2 / c3 / c5)")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     args.structures_per_gpu_set = args.structures_per_gpu is not None
     if args.structures_per_gpu is None:
         args.structures_per_gpu = 64
+    args.host_binding = "not bound"
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))       # decided before anything in this process touches the GPU
@@ -450,6 +660,10 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+
+    # before the first GPU call of this rank: keep its host threads next to its GPU
+    if os.environ.get("SPRINGCRAFT_BENCH_NO_BIND") is None and (world > 1 or os.environ.get("SPRINGCRAFT_BENCH_BIND") == "1"):
+        args.host_binding = bind_rank_to_numa_node(local_rank)
 
     import torch
     import torch.distributed as dist
@@ -473,7 +687,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
 
-    out = (run_c4 if args.config == "c4" else run_c3)(args, rank, world, torch, dist)
+    out = (run_c4 if args.config == "c4" else run_batch)(args, rank, world, torch, dist)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

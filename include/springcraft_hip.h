@@ -189,6 +189,33 @@ int sc_dev_kirchhoff_f64(sc_ctx* ctx, const double* d_coord, int64_t n_atoms, in
 int sc_dev_hessian_f64(sc_ctx* ctx, const double* d_coord, int64_t n_atoms, int64_t batch,
                        const sc_ff_desc* ff, const double* d_inv_sqrt_mass, double* d_matrix);
 
+/* ---- batches of DIFFERENT structures: sizes, force fields (incl. SC_FF_TABULATED) and patches per structure --------
+ * The reference models one arbitrary structure per object (anm.py:62-63, gnm.py:58-59) with any force field
+ * (forcefield.py:117-261 PatchedForceField, :369-533 TabulatedForceField) and optional mass weighting
+ * (anm.py:89-94,112-113).  A plan stages everything but the coordinates once: every structure gets a slot of one common
+ * matrix order (`order`, 0 = dim * the largest atom count), so that ONE sc_dev_eigh_f64(ctx, d_matrix, order, count, ..)
+ * solves the whole batch.  A slot holds diag(M, D): the structure's matrix M in its leading dim * n_atoms rows / columns
+ * and a diagonal pad D whose entries lie above every eigenvalue of M (between 2 and 4 times its largest absolute row
+ * sum).  The blocks never mix, so of the slot's ascending eigenpairs the first dim * n_atoms are the structure's, with
+ * its eigenvector components in the leading dim * n_atoms columns.
+ * All descriptor pointers are HOST pointers and need not outlive sc_batch_plan_create.  For SC_FF_TABULATED the
+ * per-atom arrays of ff->tab are the structure's own; parameter tables are uploaded once per distinct host array. */
+typedef struct sc_structure_desc {
+  int64_t n_atoms;
+  const sc_ff_desc* ff;
+  const sc_patch_desc* patch; /* NULL: none */
+} sc_structure_desc;
+typedef struct sc_batch_plan sc_batch_plan;
+int sc_batch_plan_create(sc_ctx* ctx, int dim, const sc_structure_desc* structures, int64_t count, int64_t order,
+                         sc_batch_plan** out);
+/* d_coord: (sum n_atoms, 3) f64, the structures back to back.  d_inv_sqrt_mass: NULL or (sum n_atoms,).
+ * d_matrix: (count, order, order) f64.  Enqueued on the context's stream, nothing synchronises. */
+int sc_batch_plan_assemble_f64(sc_batch_plan* plan, const double* d_coord, const double* d_inv_sqrt_mass,
+                               double* d_matrix);
+int64_t sc_batch_plan_order(const sc_batch_plan* plan);
+/* Must be destroyed before its context. */
+void sc_batch_plan_destroy(sc_batch_plan* plan);
+
 /* Batched eigensolve of `batch` independent (n,n) symmetric matrices.
  * d_a: (batch,n,n), lower triangle read, DESTROYED (used as workspace).
  * d_w: (batch,n).  d_v: NULL or (batch,n,n) rows = modes. */

@@ -41,7 +41,8 @@ EXPORTED_SYMBOLS = [
     "sc_eigh_range_f64", "sc_anm_eigen_range_f64", "sc_dev_eigh_range_f64", "sc_pinvh_f64",
     "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
     "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage", "sc_last_eigh_phase_ms",
-    "sc_ctx_get_counter",
+    "sc_ctx_get_counter", "sc_batch_plan_create", "sc_batch_plan_assemble_f64", "sc_batch_plan_order",
+    "sc_batch_plan_destroy",
 ]
 
 
@@ -84,6 +85,14 @@ class PatchDesc(C.Structure):
         ("on_force_constants", C.c_void_p),
         ("base_cutoff_masks_gamma", C.c_int32),
         ("reserved", C.c_int32),
+    ]
+
+
+class StructureDesc(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_int64),
+        ("ff", C.POINTER(FFDesc)),
+        ("patch", C.POINTER(PatchDesc)),
     ]
 
 
@@ -164,6 +173,10 @@ def lib():
         "sc_last_eigh_timings": (i32, [vp, P(dbl)]),
         "sc_last_eigh_phase_ms": (i32, [vp, C.c_char_p, P(dbl)]),
         "sc_ctx_get_counter": (i32, [vp, C.c_char_p, P(i64)]),
+        "sc_batch_plan_create": (i32, [vp, i32, P(StructureDesc), i64, i64, P(vp)]),
+        "sc_batch_plan_assemble_f64": (i32, [vp, vp, vp, vp]),
+        "sc_batch_plan_order": (i64, [vp]),
+        "sc_batch_plan_destroy": (None, [vp]),
         "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
         "sc_modes_from_matrix": (i32, [vp, vp, i64, i32, P(vp)]),
         "sc_modes_destroy": (None, [vp]),

@@ -20,7 +20,8 @@ import numpy as np
 from . import _hip
 from .forcefield import device_plan
 
-__all__ = ["DeviceBatchSolver", "shard_bounds", "solve_sharded", "partition_lpt", "solve_ragged"]
+__all__ = ["DeviceBatchSolver", "RaggedBatchSolver", "shard_bounds", "solve_sharded", "partition_lpt", "size_buckets",
+           "solve_ragged"]
 
 
 def shard_bounds(n_items, world_size, rank):
@@ -35,17 +36,25 @@ class DeviceBatchSolver:
     ANM (dim=3) or GNM (dim=1) eigensolves for a batch of equally sized structures whose
     coordinates already live in HBM.  Buffers are torch CUDA tensors; all work is enqueued on
     torch's current stream through a ``sc_ctx`` bound to that stream.
+
+    ``masses``: None, or (batch, n_atoms) / (n_atoms,) atomic masses: the matrices are mass-weighted as
+    ``ANM.hessian`` / ``GNM.kirchhoff`` do (anm.py:89-94,112-113; gnm.py:85-87,104-105).
+    ``subset_by_index=(lo, hi)``: only the eigenpairs with ascending index lo..hi (inclusive) through the
+    partial-spectrum path (no reference counterpart; BASELINE config 5): ``w`` is (batch, m), ``v`` (batch, m, n).
+    Structures of different sizes, patched or tabulated force fields: :class:`RaggedBatchSolver`.
     """
 
-    def __init__(self, n_atoms, batch, force_field, dim=3, device=None, want_vectors=True):
+    def __init__(self, n_atoms, batch, force_field, dim=3, device=None, want_vectors=True, masses=None,
+                 subset_by_index=None):
         import torch
 
         self.torch = torch
         self.n_atoms, self.batch, self.dim = int(n_atoms), int(batch), int(dim)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         ff_desc, patch, fused = device_plan(force_field)
-        if not fused or patch is not None:
-            raise ValueError("the batched device path supports Invariant / Hinsen / ParameterFree force fields")
+        if not fused or patch is not None or ff_desc.kind == _hip.SC_FF_TABULATED:
+            raise ValueError("DeviceBatchSolver takes Invariant / Hinsen / ParameterFree force fields; use "
+                             "RaggedBatchSolver for patched or tabulated ones")
         self._ff = ff_desc
         self._L = _hip.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -53,48 +62,223 @@ class DeviceBatchSolver:
         m = self.n_atoms * self.dim
         self.m = m
         f64 = torch.float64
+        self.subset = None
+        nvec = m
+        if subset_by_index is not None:
+            lo, hi = int(subset_by_index[0]), int(subset_by_index[1])
+            if not 0 <= lo <= hi < m:
+                raise ValueError(f"subset_by_index {subset_by_index} outside 0..{m - 1}")
+            self.subset = (lo, hi)
+            nvec = hi - lo + 1
         self.matrix = torch.empty((self.batch, m, m), dtype=f64, device=self.device)
-        self.w = torch.empty((self.batch, m), dtype=f64, device=self.device)
-        self.v = torch.empty((self.batch, m, m), dtype=f64, device=self.device) if want_vectors else None
+        self.w = torch.empty((self.batch, nvec), dtype=f64, device=self.device)
+        self.v = torch.empty((self.batch, nvec, m), dtype=f64, device=self.device) if want_vectors else None
+        self.inv_sqrt_mass = None
+        if masses is not None:
+            mm = torch.as_tensor(np.asarray(masses, dtype=np.float64) if not torch.is_tensor(masses) else masses,
+                                 dtype=f64, device=self.device)
+            if mm.ndim == 1:
+                mm = mm[None, :].expand(self.batch, -1)
+            if tuple(mm.shape) != (self.batch, self.n_atoms):
+                raise IndexError(f"{tuple(mm.shape)} masses for a batch of {self.batch} x {self.n_atoms} atoms")
+            if bool((mm == 0).any()):
+                raise ValueError("masses must not be 0")          # anm.py:85-86
+            self.inv_sqrt_mass = (1.0 / torch.sqrt(mm)).contiguous()
 
     def set_profiling(self, on):
         self.ctx.check(self._L.sc_ctx_set_profiling(self.ctx.handle, 1 if on else 0))
 
     def last_timings(self):
-        t = (C.c_double * 6)()
-        self.ctx.check(self._L.sc_last_eigh_timings(self.ctx.handle, t))
-        out = {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2]}
-        if t[5] > 0:   # two-stage tridiagonalisation
-            out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_apply_ms=t[5])
-            for name in ("panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update"):
-                ms = C.c_double(0.0)
-                if self._L.sc_last_eigh_phase_ms(self.ctx.handle, name.encode(), C.byref(ms)) == 0:
-                    out[name + "_ms"] = ms.value
-        else:
-            out.update(two_stage=False, symv_ms=t[3], syr2k_ms=t[4])
-        return out
+        return _last_timings(self.ctx, self._L)
 
     def assemble(self, coord):
         """coord: (batch, n_atoms, 3) float64 CUDA tensor -> self.matrix (Hessian / Kirchhoff)."""
         assert coord.is_cuda and coord.dtype == self.torch.float64 and coord.is_contiguous()
         assert tuple(coord.shape) == (self.batch, self.n_atoms, 3)
         fn = self._L.sc_dev_hessian_f64 if self.dim == 3 else self._L.sc_dev_kirchhoff_f64
+        wp = C.c_void_p(self.inv_sqrt_mass.data_ptr()) if self.inv_sqrt_mass is not None else None
         self.ctx.check(fn(self.ctx.handle, C.c_void_p(coord.data_ptr()), self.n_atoms, self.batch,
-                          C.byref(self._ff), None, C.c_void_p(self.matrix.data_ptr())))
+                          C.byref(self._ff), wp, C.c_void_p(self.matrix.data_ptr())))
         return self.matrix
 
     def eigh(self):
         """Eigendecompose self.matrix (destroyed) -> (w, v) tensors; v rows are modes (nma.py:63)."""
         vp = C.c_void_p(self.v.data_ptr()) if self.v is not None else None
-        self.ctx.check(self._L.sc_dev_eigh_f64(self.ctx.handle, C.c_void_p(self.matrix.data_ptr()), self.m,
+        if self.subset is None:
+            self.ctx.check(self._L.sc_dev_eigh_f64(self.ctx.handle, C.c_void_p(self.matrix.data_ptr()), self.m,
+                                                   self.batch, C.c_void_p(self.w.data_ptr()), vp))
+        else:
+            self.ctx.check(self._L.sc_dev_eigh_range_f64(self.ctx.handle, C.c_void_p(self.matrix.data_ptr()), self.m,
+                                                         self.batch, self.subset[0], self.subset[1],
+                                                         C.c_void_p(self.w.data_ptr()), vp))
+        return self.w, self.v
+
+    def solve(self, coord):
+        """One pass of the hot path over the batch: assembly + eigensolve, all on device."""
+        self.assemble(coord)
+        return self.eigh()
+
+
+class RaggedBatchSolver:
+    """
+    ONE batched solve for structures that differ: in size, in force field -- any built-in one,
+    :class:`TabulatedForceField` (forcefield.py:369-533) and :class:`PatchedForceField` (forcefield.py:117-261) around
+    those included -- and in their masses (anm.py:89-94).  The reference models one arbitrary structure per object
+    (anm.py:62-63); here every structure gets a slot of one common matrix order in a single batched eigensolve
+    (``sc_batch_plan_*`` in the C ABI, which documents the exact padding of the slots).
+
+    sizes         atom counts, one per structure
+    force_fields  one force field for all structures (only if it is not bound to particular atoms) or one per structure
+    masses        None, or one entry per structure: None or an (n_atoms,) array
+    order         common matrix order, default dim * max(sizes)
+
+    ``solve(coord)`` takes the structures' coordinates back to back, (sum(sizes), 3) float64 on the device, and returns
+    the padded result tensors (w (B, order), v (B, order, order)); ``results()`` slices them into per-structure views
+    (w_i (dim n_i,), v_i (dim n_i, dim n_i), rows = modes as nma.py:63).
+    """
+
+    def __init__(self, sizes, force_fields, dim=3, masses=None, device=None, want_vectors=True, order=None):
+        import torch
+
+        self.torch = torch
+        self.sizes = [int(n) for n in sizes]
+        self.batch, self.dim = len(self.sizes), int(dim)
+        if self.batch == 0:
+            raise ValueError("no structures")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if not isinstance(force_fields, (list, tuple)):
+            force_fields = [force_fields] * self.batch
+        if len(force_fields) != self.batch:
+            raise ValueError(f"{len(force_fields)} force fields for {self.batch} structures")
+        self._L = _hip.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = _hip.Context(self.device.index, stream=stream)
+        self._keep = []          # descriptor memory must outlive sc_batch_plan_create
+        descs = (_hip.StructureDesc * self.batch)()
+        plans = {}
+        for b, (n, ff) in enumerate(zip(self.sizes, force_fields)):
+            if ff.natoms is not None and ff.natoms != n:
+                raise ValueError(f"structure {b}: the force field was built for {ff.natoms} atoms, the structure has {n}")
+            if id(ff) not in plans:
+                ff_desc, patch, fused = device_plan(ff)
+                if not fused:
+                    raise ValueError(f"structure {b}: {type(ff).__name__} needs the host-callback path "
+                                     "(force_constant() in Python), which has no batched form")
+                pd = None
+                if patch is not None:
+                    pd = _hip.make_patch_desc(patch[0], patch[1], patch[2], patch[3], patch[4], self._keep)
+                plans[id(ff)] = (ff_desc, pd)
+                self._keep += [ff_desc, pd, ff]
+            ff_desc, pd = plans[id(ff)]
+            descs[b].n_atoms = n
+            descs[b].ff = C.pointer(ff_desc)
+            descs[b].patch = C.pointer(pd) if pd is not None else None
+        h = C.c_void_p()
+        self.ctx.check(self._L.sc_batch_plan_create(self.ctx.handle, self.dim, descs, self.batch,
+                                                    0 if order is None else int(order), C.byref(h)))
+        self._plan = h
+        self.order = int(self._L.sc_batch_plan_order(h))
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        f64 = torch.float64
+        m = self.order
+        self.matrix = torch.empty((self.batch, m, m), dtype=f64, device=self.device)
+        self.w = torch.empty((self.batch, m), dtype=f64, device=self.device)
+        self.v = torch.empty((self.batch, m, m), dtype=f64, device=self.device) if want_vectors else None
+        self.inv_sqrt_mass = None
+        if masses is not None:
+            if len(masses) != self.batch:
+                raise IndexError(f"{len(masses)} mass entries for {self.batch} structures")
+            packed = np.ones(int(self.offsets[-1]))
+            for b, mb in enumerate(masses):
+                if mb is None:
+                    continue
+                mb = np.asarray(mb, dtype=np.float64)
+                if mb.shape != (self.sizes[b],):
+                    raise IndexError(f"structure {b}: {mb.shape} masses for {self.sizes[b]} atoms")   # anm.py:81-84
+                if np.any(mb == 0):
+                    raise ValueError("masses must not be 0")                                            # anm.py:85-86
+                packed[self.offsets[b]: self.offsets[b + 1]] = 1.0 / np.sqrt(mb)
+            self.inv_sqrt_mass = torch.from_numpy(packed).to(self.device)
+
+    def set_profiling(self, on):
+        self.ctx.check(self._L.sc_ctx_set_profiling(self.ctx.handle, 1 if on else 0))
+
+    def last_timings(self):
+        return _last_timings(self.ctx, self._L)
+
+    def assemble(self, coord):
+        """coord: (sum(sizes), 3) float64 CUDA tensor -> self.matrix, one padded slot per structure."""
+        assert coord.is_cuda and coord.dtype == self.torch.float64 and coord.is_contiguous()
+        assert tuple(coord.shape) == (int(self.offsets[-1]), 3)
+        wp = C.c_void_p(self.inv_sqrt_mass.data_ptr()) if self.inv_sqrt_mass is not None else None
+        self.ctx.check(self._L.sc_batch_plan_assemble_f64(self._plan, C.c_void_p(coord.data_ptr()), wp,
+                                                          C.c_void_p(self.matrix.data_ptr())))
+        return self.matrix
+
+    def eigh(self):
+        vp = C.c_void_p(self.v.data_ptr()) if self.v is not None else None
+        self.ctx.check(self._L.sc_dev_eigh_f64(self.ctx.handle, C.c_void_p(self.matrix.data_ptr()), self.order,
                                                self.batch, C.c_void_p(self.w.data_ptr()), vp))
         return self.w, self.v
 
     def solve(self, coord):
-        """One pass of the hot path over the batch: assembly + full eigensolve, all on device."""
-        self.last_coord = coord
         self.assemble(coord)
         return self.eigh()
+
+    def results(self):
+        """Per-structure views of the last solve: [(w_i, v_i or None), ...]."""
+        out = []
+        for b, n in enumerate(self.sizes):
+            m = self.dim * n
+            out.append((self.w[b, :m], self.v[b, :m, :m] if self.v is not None else None))
+        return out
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None and self._plan.value:
+            self._L.sc_batch_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def size_buckets(sizes, max_flop_ratio=1.25):
+    """
+    Groups structures whose sizes are close enough to share one padded batch: sorted by size, largest first, a bucket
+    takes every structure with (N_max / N)^3 <= max_flop_ratio (the eigensolve costs ~ order^3, so no member pays more
+    than that factor for its padding).  Returns lists of item indices, each in ascending item order; deterministic.
+    """
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    buckets, cur, n_max = [], [], None
+    for i in order:
+        if cur and (n_max / sizes[i]) ** 3 > max_flop_ratio:
+            buckets.append(sorted(cur))
+            cur = []
+        if not cur:
+            n_max = sizes[i]
+        cur.append(i)
+    if cur:
+        buckets.append(sorted(cur))
+    return buckets
+
+
+def _last_timings(ctx, L):
+    """Phase durations (ms) of the context's most recent profiled eigensolve as a dict."""
+    t = (C.c_double * 6)()
+    ctx.check(L.sc_last_eigh_timings(ctx.handle, t))
+    out = {"tridiag_ms": t[0], "tridiag_eigen_ms": t[1], "backtransform_ms": t[2]}
+    if t[5] > 0:   # two-stage tridiagonalisation
+        out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_apply_ms=t[5])
+    else:
+        out.update(two_stage=False, symv_ms=t[3], syr2k_ms=t[4])
+    for name in ("panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update", "stein"):
+        ms = C.c_double(0.0)
+        if L.sc_last_eigh_phase_ms(ctx.handle, name.encode(), C.byref(ms)) == 0 and name + "_ms" not in out:
+            out[name + "_ms"] = ms.value
+    return out
 
 
 def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, solver_factory=None, solver=None):
@@ -200,7 +384,7 @@ def partition_lpt(costs, n_bins):
     return [sorted(b) for b in bins]
 
 
-def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=None, solvers=None):
+def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=None, solvers=None, max_flop_ratio=1.25):
     """
     Independent structures of DIFFERENT sizes over all ranks of ``group``.
 
@@ -264,30 +448,36 @@ def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=Non
             local[off: off + sizes[i]] = torch.from_numpy(coords_list[i]).to(dev)
             off += sizes[i]
 
-    # ---- local solves, one batch per distinct size --------------------------------------------------------------
+    # ---- local solves: one padded batch per bucket of similar sizes (injected CPU solvers: one per distinct size) ------
     offsets, off = {}, 0
     for i in mine:
         offsets[i] = off
         off += sizes[i]
     w_local = torch.zeros(pad_atoms * dim, dtype=torch.float64, device=dev)
     results = {}
-    for n_atoms in sorted({sizes[i] for i in mine}):
-        items = [i for i in mine if sizes[i] == n_atoms]
-        batch = torch.stack([local[offsets[i]: offsets[i] + n_atoms] for i in items]).contiguous()
-        if solver_factory is not None:
+    if solver_factory is not None:
+        for n_atoms in sorted({sizes[i] for i in mine}):
+            items = [i for i in mine if sizes[i] == n_atoms]
+            batch = torch.stack([local[offsets[i]: offsets[i] + n_atoms] for i in items]).contiguous()
             w_np, _ = solver_factory(n_atoms, len(items))(batch.cpu().numpy())
             w = torch.from_numpy(np.asarray(w_np))
-        else:
-            key = (n_atoms, len(items))
+            for k, i in enumerate(items):
+                w_local[offsets[i] * dim: (offsets[i] + n_atoms) * dim] = w[k].to(dev)
+                results[i] = w[k].cpu().numpy().copy()
+    else:
+        for bucket in size_buckets([sizes[i] for i in mine], max_flop_ratio):
+            items = [mine[k] for k in bucket]
+            key = tuple(sizes[i] for i in items)
             solver = solvers.get(key) if solvers is not None else None
             if solver is None:
-                solver = DeviceBatchSolver(n_atoms, len(items), force_field, dim=dim, want_vectors=False)
+                solver = RaggedBatchSolver(key, force_field, dim=dim, want_vectors=False)
                 if solvers is not None:
                     solvers[key] = solver
-            w, _ = solver.solve(batch.to(solver.device))
-        for k, i in enumerate(items):
-            w_local[offsets[i] * dim: (offsets[i] + n_atoms) * dim] = w[k].to(dev)
-            results[i] = w[k].cpu().numpy().copy()
+            packed = torch.cat([local[offsets[i]: offsets[i] + sizes[i]] for i in items]).to(solver.device).contiguous()
+            solver.solve(packed)
+            for i, (wi, _) in zip(items, solver.results()):
+                w_local[offsets[i] * dim: (offsets[i] + sizes[i]) * dim] = wi.to(dev)
+                results[i] = wi.cpu().numpy().copy()
 
     # ---- gather the packed eigenvalues ------------------------------------------------------------------------------
     if distributed:

@@ -48,6 +48,19 @@ int sc_reserve_scratch(sc_ctx* ctx, size_t bytes) {
   return SC_OK;
 }
 
+int sc_reserve_pinv(sc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinv_ws_bytes) return SC_OK;
+  if (ctx->pinv_ws) {
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipFree(ctx->pinv_ws));
+    ctx->pinv_ws = nullptr;
+    ctx->pinv_ws_bytes = 0;
+  }
+  SC_HIP(ctx, hipMalloc(&ctx->pinv_ws, bytes));
+  ctx->pinv_ws_bytes = bytes;
+  return SC_OK;
+}
+
 int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->dc_aux_bytes) return SC_OK;
   if (ctx->dc_aux) {
@@ -259,6 +272,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->dc_aux) (void)hipFree(ctx->dc_aux);
+  if (ctx->pinv_ws) (void)hipFree(ctx->pinv_ws);
   if (ctx->aux_stream) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->aux_stream);
@@ -667,6 +681,190 @@ int sc_ctx_set_two_stage(sc_ctx* ctx, int mode) {
 int64_t sc_eigh_workspace_bytes(int64_t n, int64_t batch, int want_vectors) {
   if (n <= 0 || batch <= 0) return 0;
   return (int64_t)eigh_workspace_bytes(n, batch, want_vectors != 0);
+}
+
+// ---- ragged / decorated batches ---------------------------------------------------------------------------------
+}  // extern "C"
+
+// Everything a batch of structures needs on the device besides coordinates: per-structure records (size, slot order,
+// force-field descriptor with device table pointers, patch override tables), uploaded once at plan creation.
+struct sc_batch_plan {
+  sc_ctx* ctx = nullptr;
+  int dim = 3;
+  int64_t count = 0, order = 0;
+  int max_atoms = 0;
+  bool any_patch = false, any_pad = false;
+  char* d_blob = nullptr;
+  size_t off_items = 0, off_bound = 0;
+};
+
+namespace {
+
+// Host image of the plan's device blob: take() reserves an aligned region and returns its offset.
+struct Blob {
+  std::vector<char> bytes;
+  size_t take(size_t n) {
+    const size_t off = align_up(bytes.size(), 256);
+    bytes.resize(off + n, 0);
+    return off;
+  }
+  template <typename T>
+  size_t put(const T* src, size_t count) {
+    const size_t off = take(count * sizeof(T) + 16);   // (+16: the kernels may read one element past empty tables)
+    if (count) memcpy(bytes.data() + off, src, count * sizeof(T));
+    return off;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int sc_batch_plan_create(sc_ctx* ctx, int dim, const sc_structure_desc* structures, int64_t count, int64_t order,
+                         sc_batch_plan** out) {
+  if (!ctx || !out) return SC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if ((dim != 1 && dim != 3) || count <= 0 || !structures)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments (dim %d, %lld structures)", dim, (long long)count);
+  int64_t max_atoms = 0;
+  for (int64_t b = 0; b < count; ++b) {
+    if (structures[b].n_atoms <= 0 || structures[b].n_atoms > 2000000)
+      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad atom count %lld of structure %lld",
+                          (long long)structures[b].n_atoms, (long long)b);
+    SC_TRY(check_ff(ctx, structures[b].ff));
+    max_atoms = std::max(max_atoms, structures[b].n_atoms);
+  }
+  if (order == 0) order = dim * max_atoms;
+  if (order < dim * max_atoms || order > 46000)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "slot order %lld does not hold %d x %lld rows (or exceeds 46000)",
+                        (long long)order, dim, (long long)max_atoms);
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+
+  Blob blob;
+  const size_t isz = asm_item_bytes();
+  const size_t off_items = blob.take(isz * (size_t)count);
+  const size_t off_bound = blob.take(8 * (size_t)count);
+  const size_t off_zero = blob.take(4 * ((size_t)max_atoms + 2));   // empty patch tables: shut = 0, row_ptr = 0
+  struct Rec {
+    sc_ff_desc ff; sc_tab_desc tab; bool has_tab = false;
+    size_t o_edges = 0, o_tables = 0, o_type = 0, o_chain = 0, o_bond = 0;
+    bool has_patch = false; int mask_gamma = 0;
+    size_t o_shut = 0, o_rp = 0, o_col = 0, o_flag = 0, o_gam = 0;
+  };
+  std::vector<Rec> recs((size_t)count);
+  // parameter tables are shared by every structure that points at the same host arrays
+  std::map<std::pair<const void*, int>, std::pair<size_t, size_t>> tables;   // (bonded ptr, bins) -> (edges, tables)
+  bool any_patch = false, any_pad = false;
+  for (int64_t b = 0; b < count; ++b) {
+    const sc_structure_desc& sd = structures[b];
+    Rec& r = recs[(size_t)b];
+    const size_t n = (size_t)sd.n_atoms;
+    r.ff = *sd.ff;
+    if (dim * sd.n_atoms < order) any_pad = true;
+    if (sd.ff->kind == SC_FF_TABULATED) {
+      const sc_tab_desc* t = sd.ff->tab;
+      const size_t nb = (size_t)t->n_bins;
+      for (size_t i = 0; i < n; ++i)
+        if (t->atom_type[i] < 0 || t->atom_type[i] >= 20)
+          return sc_set_error(ctx, SC_ERR_INDEX, "amino-acid type %d of atom %lld of structure %lld out of range",
+                              t->atom_type[i], (long long)i, (long long)b);
+      r.has_tab = true;
+      r.tab = *t;
+      const auto key = std::make_pair((const void*)t->bonded, t->n_bins);
+      auto it = tables.find(key);
+      if (it == tables.end()) {
+        const size_t oe = blob.take(nb * 8 + 16);
+        if (t->edges_sq) memcpy(blob.bytes.data() + oe, t->edges_sq, nb * 8);
+        const size_t ot = blob.take(3 * 400 * nb * 4);
+        memcpy(blob.bytes.data() + ot, t->bonded, 400 * nb * 4);
+        memcpy(blob.bytes.data() + ot + 400 * nb * 4, t->intra_chain, 400 * nb * 4);
+        memcpy(blob.bytes.data() + ot + 800 * nb * 4, t->inter_chain, 400 * nb * 4);
+        it = tables.emplace(key, std::make_pair(oe, ot)).first;
+      }
+      r.o_edges = it->second.first;
+      r.o_tables = it->second.second;
+      r.o_type = blob.put(t->atom_type, n);
+      r.o_chain = blob.put(t->chain, n);
+      r.o_bond = blob.put(t->bonded_next, n);
+    }
+    HostPatch hp;
+    SC_TRY(build_patch(ctx, sd.patch, sd.n_atoms, hp));
+    if (hp.any) {
+      any_patch = true;
+      r.has_patch = true;
+      r.mask_gamma = hp.mask_gamma;
+      r.o_shut = blob.put(hp.shut.data(), hp.shut.size());
+      r.o_rp = blob.put(hp.row_ptr.data(), hp.row_ptr.size());
+      r.o_col = blob.put(hp.col.data(), hp.col.size());
+      r.o_flag = blob.put(hp.flag.data(), hp.flag.size());
+      r.o_gam = blob.put(hp.gam.data(), hp.gam.size());
+    }
+  }
+  char* d_blob = nullptr;
+  SC_HIP(ctx, hipMalloc((void**)&d_blob, align_up(blob.bytes.size(), 256)));
+  // the item records hold device addresses: fill them now that the blob's base is known
+  long long atom_off = 0;
+  for (int64_t b = 0; b < count; ++b) {
+    Rec& r = recs[(size_t)b];
+    const size_t nb = r.has_tab ? (size_t)r.tab.n_bins : 0;
+    sc_ff_desc ffd = r.ff;
+    sc_tab_desc td{};
+    if (r.has_tab) {
+      td = r.tab;
+      td.edges_sq = reinterpret_cast<const double*>(d_blob + r.o_edges);
+      td.bonded = reinterpret_cast<const float*>(d_blob + r.o_tables);
+      td.intra_chain = td.bonded + 400 * nb;
+      td.inter_chain = td.bonded + 800 * nb;
+      td.atom_type = reinterpret_cast<const int32_t*>(d_blob + r.o_type);
+      td.chain = reinterpret_cast<const int32_t*>(d_blob + r.o_chain);
+      td.bonded_next = reinterpret_cast<const uint8_t*>(d_blob + r.o_bond);
+      ffd.tab = &td;
+    }
+    PatchDev pdv{};
+    if (r.has_patch) {
+      pdv = PatchDev{reinterpret_cast<const uint8_t*>(d_blob + r.o_shut), reinterpret_cast<const int32_t*>(d_blob + r.o_rp),
+                     reinterpret_cast<const int32_t*>(d_blob + r.o_col), reinterpret_cast<const int8_t*>(d_blob + r.o_flag),
+                     reinterpret_cast<const double*>(d_blob + r.o_gam), r.mask_gamma};
+    } else {
+      pdv = PatchDev{reinterpret_cast<const uint8_t*>(d_blob + off_zero), reinterpret_cast<const int32_t*>(d_blob + off_zero),
+                     reinterpret_cast<const int32_t*>(d_blob + off_zero), reinterpret_cast<const int8_t*>(d_blob + off_zero),
+                     reinterpret_cast<const double*>(d_blob + off_zero), 0};
+    }
+    asm_item_fill(blob.bytes.data() + off_items + isz * (size_t)b, atom_off, (int)structures[b].n_atoms, (int)order, ffd, pdv);
+    atom_off += structures[b].n_atoms;
+  }
+  if (hipMemcpy(d_blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d_blob);
+    return sc_set_error(ctx, SC_ERR_HIP, "upload of the batch plan failed");
+  }
+  sc_batch_plan* plan = new (std::nothrow) sc_batch_plan();
+  if (!plan) { (void)hipFree(d_blob); return SC_ERR_NOMEM; }
+  plan->ctx = ctx; plan->dim = dim; plan->count = count; plan->order = order; plan->max_atoms = (int)max_atoms;
+  plan->any_patch = any_patch; plan->any_pad = any_pad;
+  plan->d_blob = d_blob; plan->off_items = off_items; plan->off_bound = off_bound;
+  *out = plan;
+  return SC_OK;
+}
+
+int sc_batch_plan_assemble_f64(sc_batch_plan* plan, const double* d_coord, const double* d_inv_sqrt_mass,
+                               double* d_matrix) {
+  if (!plan) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = plan->ctx;
+  if (!d_coord || !d_matrix) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_assemble_items(ctx, plan->dim, plan->d_blob + plan->off_items, plan->count, plan->max_atoms,
+                               plan->any_patch, plan->any_pad, d_coord, d_inv_sqrt_mass, d_matrix,
+                               reinterpret_cast<unsigned long long*>(plan->d_blob + plan->off_bound));
+}
+
+int64_t sc_batch_plan_order(const sc_batch_plan* plan) { return plan ? plan->order : 0; }
+
+void sc_batch_plan_destroy(sc_batch_plan* plan) {
+  if (!plan) return;
+  (void)hipSetDevice(plan->ctx->device);
+  (void)hipStreamSynchronize(plan->ctx->stream);
+  if (plan->d_blob) (void)hipFree(plan->d_blob);
+  delete plan;
 }
 
 // ---- device-resident eigenpairs --------------------------------------------------------------------------

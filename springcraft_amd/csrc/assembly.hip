@@ -26,6 +26,16 @@ struct FFDev {
   const unsigned char* bonded_next;
 };
 
+// One structure of a ragged / decorated batch (sc_batch_plan, api.hip): its own size, force field and patches; the
+// coordinates / weights / matrices of all structures sit in three buffers the launch gets as base pointers.
+struct AsmItem {
+  long long atom_off;   // first atom of this structure in the packed coordinate / weight buffers
+  int n;                // atoms
+  int ld;               // order of the matrix slot (>= dim * n; the slot is padded, see k_pad_fill)
+  FFDev ff;
+  PatchDev patch;       // empty tables (all zero) when the structure has no patches but another one of the batch has
+};
+
 // TabulatedForceField.force_constant (forcefield.py:515-533) from the type tables
 __device__ __forceinline__ double tab_gamma(const FFDev& ff, int i, int j, double d2) {
   int bin = 0;
@@ -107,19 +117,40 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /*[4]*/) {
 // One block = TI consecutive atoms i (matrix rows) x all columns; thread = column j in a 256-wide
 // tile.  Row coordinates are wave-uniform registers, column coordinates are read once per tile and
 // reused for the TI rows.  Stores are 8 B per lane, contiguous along the row.
-template <int TI, bool PATCH>
-__global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ coord_all, int n,
-                                                   FFDev ff, PatchDev patch,
+template <int TI, bool PATCH, bool ITEMS>
+__global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ coord_all, int n_arg,
+                                                   FFDev ff_arg, PatchDev patch_arg,
                                                    const double* __restrict__ w_all,
                                                    double* __restrict__ k_all,
-                                                   long long* __restrict__ counts_all) {
+                                                   long long* __restrict__ counts_all,
+                                                   const AsmItem* __restrict__ items) {
   __shared__ double red[4];
   const size_t b = blockIdx.y;
-  const double* coord = coord_all + b * (size_t)n * 3;
-  const double* w = w_all ? w_all + b * (size_t)n : nullptr;
-  double* K = k_all ? k_all + b * (size_t)n * n : nullptr;
-  long long* counts = counts_all ? counts_all + b * (size_t)n : nullptr;
+  int n = n_arg;
+  size_t ld = (size_t)n_arg;
+  FFDev ff = ff_arg;
+  PatchDev patch = patch_arg;
+  const double* coord;
+  const double* w;
+  double* K;
+  long long* counts = nullptr;
+  if (ITEMS) {
+    const AsmItem it = items[b];
+    n = it.n;
+    ld = (size_t)it.ld;
+    ff = it.ff;
+    patch = it.patch;
+    coord = coord_all + (size_t)it.atom_off * 3;
+    w = w_all ? w_all + it.atom_off : nullptr;
+    K = k_all + b * ld * ld;
+  } else {
+    coord = coord_all + b * (size_t)n * 3;
+    w = w_all ? w_all + b * (size_t)n : nullptr;
+    K = k_all ? k_all + b * (size_t)n * n : nullptr;
+    counts = counts_all ? counts_all + b * (size_t)n : nullptr;
+  }
   const int i0 = blockIdx.x * TI;
+  if (i0 >= n) return;   // (ragged batches: the grid covers the largest structure)
 
   double cix[TI], ciy[TI], ciz[TI], wi[TI];
   int rbeg[TI], rend[TI];
@@ -160,7 +191,7 @@ __global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ co
         if (K && j != i) {
           double v = c ? -g : 0.0;                     // interaction.py:50
           if (w) v = v * (wi[t] * wj);                 // gnm.py:104-105
-          K[(size_t)i * n + j] = v;
+          K[(size_t)i * ld + j] = v;
         }
       }
     }
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ co
       if (K) {
         double v = s;                                  // -sum(-gamma), interaction.py:52
         if (w) v = v * (wi[t] * wi[t]);
-        K[(size_t)i * n + i] = v;
+        K[(size_t)i * ld + i] = v;
       }
       if (counts) counts[i] = (long long)c;
     }
@@ -187,19 +218,38 @@ __global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ co
 // and the block then streams those segments out with fully contiguous 8-B-per-lane stores (a lane
 // writing its own 3 doubles would issue 24-B-strided partial-line stores).  Diagonal blocks are the
 // negated row sums, accumulated in registers and reduced in a fixed order (deterministic).
-template <int TI, bool PATCH>
-__global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coord_all, int n,
-                                                 FFDev ff, PatchDev patch,
+template <int TI, bool PATCH, bool ITEMS>
+__global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coord_all, int n_arg,
+                                                 FFDev ff_arg, PatchDev patch_arg,
                                                  const double* __restrict__ w_all,
-                                                 double* __restrict__ h_all) {
+                                                 double* __restrict__ h_all,
+                                                 const AsmItem* __restrict__ items) {
   __shared__ double tile[2][3][768];
   __shared__ double red[4];
   const size_t b = blockIdx.y;
-  const double* coord = coord_all + b * (size_t)n * 3;
-  const double* w = w_all ? w_all + b * (size_t)n : nullptr;
+  int n = n_arg;
+  FFDev ff = ff_arg;
+  PatchDev patch = patch_arg;
+  const double* coord;
+  const double* w;
+  size_t ld;   // row stride of the matrix slot
+  if (ITEMS) {
+    const AsmItem it = items[b];
+    n = it.n;
+    ld = (size_t)it.ld;
+    ff = it.ff;
+    patch = it.patch;
+    coord = coord_all + (size_t)it.atom_off * 3;
+    w = w_all ? w_all + it.atom_off : nullptr;
+  } else {
+    ld = (size_t)n * 3;
+    coord = coord_all + b * (size_t)n * 3;
+    w = w_all ? w_all + b * (size_t)n : nullptr;
+  }
   const size_t n3 = (size_t)n * 3;
-  double* H = h_all + b * n3 * n3;
+  double* H = h_all + b * ld * ld;
   const int i0 = blockIdx.x * TI;
+  if (i0 >= n) return;   // (ragged batches: the grid covers the largest structure)
   const int tid = threadIdx.x;
 
   double cix[TI], ciy[TI], ciz[TI], wi[TI];
@@ -271,7 +321,7 @@ __global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coor
       const size_t col0 = (size_t)tl * 768;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        double* row = H + ((size_t)3 * i + a) * n3;
+        double* row = H + ((size_t)3 * i + a) * ld;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int c = q * 256 + tid;
@@ -292,7 +342,7 @@ __global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coor
       if (tid == 0 && i < n) {
         double v = -s;
         if (w) v = v * (wi[t] * wi[t]);
-        H[((size_t)3 * i + q / 3) * n3 + (size_t)3 * i + q % 3] = v;
+        H[((size_t)3 * i + q / 3) * ld + (size_t)3 * i + q % 3] = v;
       }
     }
   }
@@ -390,6 +440,53 @@ __global__ void k_hessian_diag(int n, double* __restrict__ H) {
   H[(3 * i + a) * n3 + c] = -s;
 }
 
+// ---- padded slots of a ragged batch ----------------------------------------------------------------------------
+// Structures of different sizes share ONE batched eigensolve of order ld: slot b holds diag(M_b, D_b) with M_b the
+// structure's m x m matrix (m = dim * atoms) and D_b a diagonal block with entries above every eigenvalue of M_b.  The
+// two blocks never mix (the reflectors of the tridiagonalisation have exact zeros in the padded rows, the tridiagonal
+// matrix splits exactly at m), so the first m eigenpairs of the slot are those of M_b, eigenvectors in the leading m
+// components.  The pad values stay within a factor ~2 of ||M_b||: the solver's tolerances scale with the norm of the
+// whole slot, so a huge pad value would cost M_b's small eigenvalues their accuracy.
+//   k_slot_bound: sigma_b = 2 max_i sum_j |M_b[i, j]| (Gershgorin: every |eigenvalue| <= the largest absolute row sum)
+//   k_pad_fill:   zeros beside and below M_b, pad entry p = sigma_b (1 + (p + 1) / (pad count))   (distinct, ascending)
+__global__ __launch_bounds__(256) void k_slot_bound(const double* __restrict__ m_all, const AsmItem* __restrict__ items,
+                                                    int dim, unsigned long long* __restrict__ bound_bits) {
+  const AsmItem it = items[blockIdx.y];
+  const size_t ld = (size_t)it.ld;
+  const int m = dim * it.n;
+  const double* M = m_all + (size_t)blockIdx.y * ld * ld;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;   // wave-uniform
+  double s = 0.0;
+  for (int j = lane; j < m; j += 64) s += fabs(M[(size_t)row * ld + j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  // bit patterns of non-negative doubles are ordered like the values (a NaN row sum has the largest pattern: the slot
+  // bound becomes NaN, the pad entries NaN, and the solver rejects the matrix as it does for any non-finite input)
+  if (lane == 0) atomicMax(bound_bits + blockIdx.y, (unsigned long long)__double_as_longlong(s));
+}
+
+__global__ __launch_bounds__(256) void k_pad_fill(double* __restrict__ m_all, const AsmItem* __restrict__ items, int dim,
+                                                  const unsigned long long* __restrict__ bound_bits) {
+  const AsmItem it = items[blockIdx.y];
+  const size_t ld = (size_t)it.ld;
+  const int m = dim * it.n;
+  const int npad = it.ld - m;
+  if (npad <= 0) return;
+  double* M = m_all + (size_t)blockIdx.y * ld * ld;
+  const double bound = __longlong_as_double((long long)bound_bits[blockIdx.y]);
+  const double sigma = bound > 0.0 ? 2.0 * bound : (bound == 0.0 ? 1.0 : bound);
+  // region 1: rows [0, m) x columns [m, ld); region 2: rows [m, ld) x all columns
+  const size_t r1 = (size_t)m * npad, total = r1 + (size_t)npad * ld;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    size_t r, c;
+    if (idx < r1) { r = idx / npad; c = m + idx % npad; }
+    else { const size_t k = idx - r1; r = m + k / ld; c = k % ld; }
+    M[r * ld + c] = (r == c) ? sigma * (1.0 + (double)(r - m + 1) / (double)npad) : 0.0;
+  }
+}
+
 // ff.tab, when set, has already been replaced by a descriptor holding DEVICE pointers (api.hip:stage_tab)
 FFDev make_ff(const sc_ff_desc& ff) {
   FFDev d{};
@@ -418,11 +515,11 @@ int launch_kirchhoff(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batc
   PatchDev p{};
   if (patch) {
     p = *patch;
-    hipLaunchKernelGGL((k_kirchhoff<TI, true>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
-                       make_ff(ff), p, d_w, d_k, (long long*)d_counts);
+    hipLaunchKernelGGL((k_kirchhoff<TI, true, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_k, (long long*)d_counts, (const AsmItem*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_kirchhoff<TI, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
-                       make_ff(ff), p, d_w, d_k, (long long*)d_counts);
+    hipLaunchKernelGGL((k_kirchhoff<TI, false, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_k, (long long*)d_counts, (const AsmItem*)nullptr);
   }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
@@ -441,11 +538,11 @@ int launch_hessian(sc_ctx* ctx, const double* d_coord, int64_t n, int64_t batch,
   PatchDev p{};
   if (patch) {
     p = *patch;
-    hipLaunchKernelGGL((k_hessian<TI, true>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
-                       make_ff(ff), p, d_w, d_h);
+    hipLaunchKernelGGL((k_hessian<TI, true, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_h, (const AsmItem*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_hessian<TI, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
-                       make_ff(ff), p, d_w, d_h);
+    hipLaunchKernelGGL((k_hessian<TI, false, false>), grid, dim3(256), 0, ctx->stream, d_coord, (int)n,
+                       make_ff(ff), p, d_w, d_h, (const AsmItem*)nullptr);
   }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
@@ -525,6 +622,54 @@ int launch_hessian_from_pairs(sc_ctx* ctx, const double* d_coord, int64_t n, con
                        d_gamma, d_h);
   hipLaunchKernelGGL(k_hessian_diag, dim3((unsigned)((9 * n + 255) / 256)), dim3(256), 0,
                      ctx->stream, (int)n, d_h);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// ---- ragged / decorated batches (sc_batch_plan) -----------------------------------------------------------------
+size_t asm_item_bytes() { return sizeof(AsmItem); }
+
+void asm_item_fill(void* dst, long long atom_off, int n, int ld, const sc_ff_desc& ff_dev, const PatchDev& patch) {
+  AsmItem it{};
+  it.atom_off = atom_off;
+  it.n = n;
+  it.ld = ld;
+  it.ff = make_ff(ff_dev);
+  it.patch = patch;
+  *reinterpret_cast<AsmItem*>(dst) = it;
+}
+
+int launch_assemble_items(sc_ctx* ctx, int dim, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                          bool any_pad, const double* d_coord, const double* d_w, double* d_matrix,
+                          unsigned long long* d_bound_bits) {
+  if (count <= 0 || max_atoms <= 0) return SC_OK;
+  const AsmItem* items = reinterpret_cast<const AsmItem*>(d_items);
+  hipStream_t st = ctx->stream;
+  const FFDev ff0{};
+  const PatchDev p0{};
+  if (dim == 1) {
+    constexpr int TI = 4;
+    const dim3 grid((unsigned)((max_atoms + TI - 1) / TI), (unsigned)count);
+    if (any_patch)
+      hipLaunchKernelGGL((k_kirchhoff<TI, true, true>), grid, dim3(256), 0, st, d_coord, 0, ff0, p0, d_w, d_matrix,
+                         (long long*)nullptr, items);
+    else
+      hipLaunchKernelGGL((k_kirchhoff<TI, false, true>), grid, dim3(256), 0, st, d_coord, 0, ff0, p0, d_w, d_matrix,
+                         (long long*)nullptr, items);
+  } else {
+    constexpr int TI = 2;
+    const dim3 grid((unsigned)((max_atoms + TI - 1) / TI), (unsigned)count);
+    if (any_patch)
+      hipLaunchKernelGGL((k_hessian<TI, true, true>), grid, dim3(256), 0, st, d_coord, 0, ff0, p0, d_w, d_matrix, items);
+    else
+      hipLaunchKernelGGL((k_hessian<TI, false, true>), grid, dim3(256), 0, st, d_coord, 0, ff0, p0, d_w, d_matrix, items);
+  }
+  if (any_pad) {
+    SC_HIP(ctx, hipMemsetAsync(d_bound_bits, 0, sizeof(unsigned long long) * (size_t)count, st));
+    hipLaunchKernelGGL(k_slot_bound, dim3((unsigned)((dim * max_atoms + 3) / 4), (unsigned)count), dim3(256), 0, st,
+                       d_matrix, items, dim, d_bound_bits);
+    hipLaunchKernelGGL(k_pad_fill, dim3(64, (unsigned)count), dim3(256), 0, st, d_matrix, items, dim, d_bound_bits);
+  }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
 }

@@ -36,6 +36,9 @@ struct sc_ctx {
   // cannot share `scratch`, which the assembly entry points hold while they call the solver)
   void* dc_aux = nullptr;
   size_t dc_aux_bytes = 0;
+  // eigenvector / scaled-eigenvector buffers of pinvh_device (covariance properties), alive across its eigensolve
+  void* pinv_ws = nullptr;
+  size_t pinv_ws_bytes = 0;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
   // persistent bulge chase (twostage.hip): chase_ok = 0 once a chase of this context ran into its time-out (never
@@ -126,6 +129,7 @@ int sc_aux_stream(sc_ctx* ctx);   // creates aux_stream / aux_fork / aux_join if
 int sc_side_streams(sc_ctx* ctx, int count);   // makes sure side_streams / side_joins hold `count` entries
 int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
 int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes);
+int sc_reserve_pinv(sc_ctx* ctx, size_t bytes);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -157,6 +161,15 @@ int launch_kirchhoff_from_pairs(sc_ctx* ctx, int64_t n, const int64_t* d_pairs, 
 int launch_hessian_from_pairs(sc_ctx* ctx, const double* d_coord, int64_t n,
                               const int64_t* d_pairs, int64_t k, const double* d_gamma,
                               double* d_h);
+// Ragged / decorated batches (sc_batch_plan, api.hip): records of one structure each, opaque outside assembly.hip.
+size_t asm_item_bytes();
+// ff_dev: descriptor whose .tab (if any) holds DEVICE pointers; patch: device tables (empty tables when unpatched)
+void asm_item_fill(void* dst, long long atom_off, int n, int ld, const sc_ff_desc& ff_dev, const PatchDev& patch);
+// d_items: `count` records in device memory.  Writes (count, ld, ld) matrices: the structure's matrix in the leading
+// dim * n rows / columns of its slot, the rest padded (see k_pad_fill).  d_bound_bits: count uint64 of scratch.
+int launch_assemble_items(sc_ctx* ctx, int dim, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                          bool any_pad, const double* d_coord, const double* d_w, double* d_matrix,
+                          unsigned long long* d_bound_bits);
 // In-place transpose-free symmetric "row-major == column-major" note: the eigensolver reads the
 // LOWER triangle in column-major order, i.e. the UPPER triangle of the row-major matrix the
 // assembly writes; the matrices are symmetric so both views agree.

@@ -427,11 +427,11 @@ __global__ void k_pinv_scale(const double* __restrict__ q, const double* __restr
 int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_out) {
   const int n = (int)n64;
   hipStream_t st = ctx->stream;
-  // buffers: Q (n^2) | QS (n^2) | w (n) | desc -- one allocation, so a failed one leaves nothing behind (the
-  // context's cached buffers are all in use by the caller and by eigh_batched while this runs)
+  // buffers: Q (n^2) | QS (n^2) | w (n) | desc from a cached grow-only allocation of the context (its other cached
+  // buffers are all in use by the caller and by eigh_batched while this runs)
   const size_t nn = align_up(sizeof(double) * (size_t)n * n, 256), nw = align_up(sizeof(double) * (size_t)n, 256);
-  char* d_base = nullptr;
-  SC_HIP(ctx, hipMalloc((void**)&d_base, 2 * nn + nw + sizeof(GemmDesc)));
+  SC_TRY(sc_reserve_pinv(ctx, 2 * nn + nw + sizeof(GemmDesc)));
+  char* d_base = reinterpret_cast<char*>(ctx->pinv_ws);
   double* d_q = reinterpret_cast<double*>(d_base);
   double* d_qs = reinterpret_cast<double*>(d_base + nn);
   double* d_w = reinterpret_cast<double*>(d_base + 2 * nn);
@@ -446,8 +446,7 @@ int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_
     D.alpha = 1.0; D.beta = 0.0;
     if (hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, st) != hipSuccess) rc = SC_ERR_HIP;
     if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile, 1, false, false, kGemmAmBn);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;   // D is a stack object
   }
-  (void)hipFree(d_base);
   return rc;
 }

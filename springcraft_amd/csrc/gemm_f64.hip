@@ -682,6 +682,16 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
   const bool lower = lower_grid && !no_lower && layout == kGemmAmBn && !tri && !gather && split_k <= 1 && max_m == max_n;
   if (count <= 0 || max_m <= 0 || max_n <= 0) return SC_OK;
   if (split_k < 1) split_k = 1;
+  if (split_k > 65535) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "split_k %d too large", split_k);
+  // grid.z (records x K slices) is limited to 65535: longer record lists go out in chunks (the D&C merges of a batch of
+  // some thousand matrices get there)
+  if ((long long)count * split_k > 65535) {
+    const int max_rec = 65535 / split_k;
+    for (int r0 = 0; r0 < count; r0 += max_rec)
+      SC_TRY(launch_gemm_f64(ctx, d_desc + r0, std::min(max_rec, count - r0), max_m, max_n, tile, split_k, gather, tri,
+                             layout, lower_grid));
+    return SC_OK;
+  }
   hipStream_t st = ctx->stream;
   static const bool gather_old = getenv("SPRINGCRAFT_GEMM_GATHER_OLD") != nullptr;
   if (gather && !tri && layout == kGemmAmBk && gemm2_enabled() && !gather_old) {

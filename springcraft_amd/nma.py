@@ -127,8 +127,16 @@ def dcc(enm, mode_subset=None, norm=True, tem=None, tem_factors=K_B):
     """Dynamic cross-correlation between nodes over the selected modes (nma.py:233-359)."""
     _model_kind(enm)
     modes = enm._modes_device()
+    if mode_subset is None:
+        # all modes: the reference takes the covariance matrix here (nma.py:324-336), i.e. pinv(M, hermitian=True,
+        # rcond=1e-6): every mode with |lambda| > 1e-6 max|lambda| -- which drops the trivial modes and, on a nearly
+        # disconnected network, also non-trivial modes below that threshold
+        w = modes.values()
+        sel = np.nonzero(np.abs(w) > 1e-6 * np.abs(w).max())[0]
+    else:
+        sel = _mode_selection(enm, mode_subset, modes.order)
     # sum_k <v_k[a], v_k[b]> / lambda_k, normalised by sqrt(c_aa c_bb) on request
-    cov = modes.dcc(_mode_selection(enm, mode_subset, modes.order), norm)
+    cov = modes.dcc(sel, norm)
     if tem is not None:  # applied after the normalisation, as the reference does (nma.py:355-357)
         cov = cov * tem * tem_factors
     return cov

@@ -237,3 +237,33 @@ def test_device_eigenpair_cache_is_bounded(sc):
     finally:
         cache.budget = old
         cache.clear()
+
+
+def test_dcc_all_modes_follows_the_pinv_rule_on_a_nearly_disconnected_network(sc):
+    """
+    dcc() with all modes is the covariance matrix in the reference (nma.py:324-336), i.e. pinv(M, hermitian=True,
+    rcond=1e-6): on two clusters joined by one very weak spring a NON-trivial mode falls below 1e-6 * lambda_max and
+    is dropped too.  Checked against NumPy's pinv of the oracle's Kirchhoff / Hessian.
+    """
+    rs = np.random.RandomState(11)
+    a = rs.rand(12, 3) * 6.0
+    b = rs.rand(12, 3) * 6.0 + np.array([40.0, 0.0, 0.0])
+    coord = np.concatenate([a, b])
+    weak = sc.PatchedForceField(sc.InvariantForceField(9.0), contact_pair_on=np.array([[0, 12]]),
+                                force_constants=np.array([1e-9]))
+    # GNM: one inter-cluster mode of ~1e-10 next to lambda_max ~ 10
+    gnm = sc.GNM(coord, weak)
+    k = gnm.kirchhoff.copy()
+    w = np.linalg.eigvalsh(k)
+    assert np.sum(np.abs(w) <= 1e-6 * np.abs(w).max()) == 2          # the trivial mode and the weak one
+    cov = np.linalg.pinv(k, hermitian=True, rcond=1e-6)
+    d = np.sqrt(np.diag(cov))
+    assert np.allclose(sc.GNM(coord, weak).dcc(norm=False), cov, rtol=1e-8, atol=1e-10)
+    assert np.allclose(sc.GNM(coord, weak).dcc(), cov / np.outer(d, d), rtol=1e-8, atol=1e-10)
+    # ANM: trace of the 3x3 super-elements of pinv(H)
+    anm = sc.ANM(coord, weak)
+    h = anm.hessian.copy()
+    covh = np.linalg.pinv(h, hermitian=True, rcond=1e-6)
+    n = len(coord)
+    tr = covh.reshape(n, 3, n, 3).swapaxes(1, 2).trace(axis1=2, axis2=3)
+    assert np.allclose(sc.ANM(coord, weak).dcc(norm=False), tr, rtol=1e-8, atol=1e-9)

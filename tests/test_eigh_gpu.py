@@ -388,3 +388,37 @@ def test_non_finite_input_is_rejected(two_stage):
             sc.ANM(coord, sc.HinsenForceField()).eigen()
     finally:
         ctx.set_two_stage(None)
+
+
+def test_many_small_matrices_chunked_gemm_records(sc):
+    """
+    33 000 matrices of order 40 in one batched solve: the D&C merge launch then carries 66 000 GEMM records, more than
+    grid.z holds -- the launcher must split the record list (it used to fail with SC_ERR_INVALID_ARG).
+    """
+    import ctypes as C
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    n, batch = 40, 33000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn((batch, n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = a + a.transpose(1, 2)
+    keep = a.clone()
+    w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+    v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+    ctx = _hip.Context(0)
+    try:
+        ctx.check(_hip.lib().sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                             C.c_void_p(v.data_ptr())))
+        ctx.synchronize()
+    finally:
+        ctx.close()
+    r = torch.bmm(keep, v.transpose(1, 2)) - v.transpose(1, 2) * w[:, None, :]
+    assert float(r.abs().max()) <= 1e-11 * float(w.abs().max())
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    assert float((torch.bmm(v, v.transpose(1, 2)) - eye).abs().max()) <= 1e-12
+    for b in (0, batch // 2, batch - 1):
+        w_ref = np.linalg.eigvalsh(keep[b].cpu().numpy())
+        assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-12 * np.abs(w_ref).max()
