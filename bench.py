@@ -64,9 +64,9 @@ def bt2_flops(n, ncols):
     """
     k_bt2_apply, per matrix: (algorithmic, executed) flops.  Sweep s (0 .. n-3) of the bulge chase leaves reflectors
     of length min(64, n - r0) at rows r0 = s + 1 + 64 k; applying one of length L to a column costs 4 L flops.
-    The kernel applies them 64 sweeps at a time as compact-WY "diamonds" (127 x 64 parallelograms) and skips the
-    k-steps that only meet structural zeros: 80 + 104 operand fragments (16 x 4) = 2 * 64 * 184 MFMA flops per diamond and
-    column.
+    The kernel applies the 64 sweeps at one chase position (a "diamond", a 127 x 64 parallelogram) as four compact-WY
+    blocks of 16 sweeps, each meeting 5 row tiles in both products: 4 x (20 + 20) operand fragments (16 x 4) =
+    2 * 64 * 160 MFMA flops per diamond and column (round 2: one 64-sweep block, 80 + 104 fragments).
     """
     s = np.arange(0, n - 2, dtype=np.int64)
     total_len = 0
@@ -75,7 +75,7 @@ def bt2_flops(n, ncols):
         total_len += int(np.clip(n - r0, 0, 64).sum())
     ngroups = (n - 2 + 63) // 64
     ndia = sum((n - 1 - 64 * g + 63) // 64 for g in range(ngroups))
-    return 4.0 * total_len * ncols, 2.0 * 64 * (80 + 64 + 40) * ndia * ncols
+    return 4.0 * total_len * ncols, 2.0 * 64 * 160 * ndia * ncols
 
 
 def bulge_bytes(n):

@@ -115,8 +115,8 @@ struct SbLayout {
   long long ab;       // band storage 128 x n
   int ngroups;        // sweep groups (64 sweeps each)
   long long ndia;     // diamonds
-  long long vd, vt2;  // diamonds: V row-major (128 rows x 64 sweeps), V T column-major (ld 128; first-generation path only)
-  long long frag;     // diamonds: MFMA fragments of V^T and -(V T), 184 x 64 doubles each (k_dia_tfactor2 -> k_bt2_apply)
+  long long vd;       // diamonds: V row-major (128 rows x 64 sweeps)
+  long long frag;     // diamonds: MFMA fragments of V^T and -(V T), 160 x 64 doubles each (k_dia_tfactor2 -> k_bt2_apply)
   long long tau2;     // ndia x 64
 };
 // ncols: columns of Z the back-transformation will be applied to (0: eigenvalues only)

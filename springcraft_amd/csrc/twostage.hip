@@ -973,250 +973,27 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
 }
 
 // ================================================================================================================
-// Diamonds: T factor and V T.  One workgroup per (diamond, matrix).  The diamond is held compactly in LDS
-// (Vc[c][i] = V[c + i, c], the 64 entries of reflector c), G and T share one buffer (G is only read by the first
-// wave's recurrence, which then writes T over it).
-__global__ __launch_bounds__(256) void k_dia_tfactor(double* __restrict__ sb_all, SbLayout SL, int dia0) {
-  constexpr int LD = kG + 1;
-  __shared__ double Vc[kG * LD];     // Vc[c * LD + i]
-  __shared__ double GT[kG * LD];     // G[a * LD + b] (a < b), overwritten column by column with T
-  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
-  const size_t dia = (size_t)dia0 + blockIdx.x;
-  const double* vd = sb + SL.vd + dia * kDiaSize;
-  const double* tau = sb + SL.tau2 + dia * kG;
-  const int tid = threadIdx.x;
-  {
-    // row r of the diamond holds sweeps c in [r - 63, r]; lanes along c (contiguous in memory)
-    const int c = tid & 63, q = tid >> 6;
-    for (int i = q; i < kB; i += 4) Vc[c * LD + i] = vd[(size_t)(c + i) * kG + c];
-  }
-  __syncthreads();
-  // G[a, b] = v_a . v_b for a < b: rows b .. a + 63, i.e. entries i = b - a .. 63 of v_a against 0 .. of v_b
-  {
-    const int a = tid & 63, q = tid >> 6;
-    for (int b = q * 16; b < q * 16 + 16; ++b) {
-      double s = 0.0;
-      if (a < b) {
-        const int sh = b - a;
-        for (int i = sh; i < kB; ++i) s += Vc[a * LD + i] * Vc[b * LD + i - sh];
-      }
-      GT[a * LD + b] = s;
-    }
-  }
-  __syncthreads();
-  // T (larft, forward columnwise): T[0:q, q] = -tau_q T[0:q, 0:q] G[0:q, q], T[q, q] = tau_q.  Lane a of the first wave
-  // keeps row a of T in registers (T[a, l] = 0 for l < a), G comes as LDS broadcasts: 2016 fully unrolled FMAs per lane
-  // and no synchronisation inside the recurrence.
-  if (tid < kG) {
-    double trow[kG];
-#pragma unroll
-    for (int qq = 0; qq < kG; ++qq) {
-      double s = 0.0;
-#pragma unroll
-      for (int l = 0; l < qq; ++l) s += trow[l] * GT[l * LD + qq];
-      const double tq = tau[qq];
-      trow[qq] = tid < qq ? -tq * s : (tid == qq ? tq : 0.0);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): every lane has finished reading G before T overwrites it
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int qq = 0; qq < kG; ++qq) GT[tid * LD + qq] = trow[qq];
-  }
-  __syncthreads();
-  // VT[r, c] = sum_l V[r, l] T[l, c]   (128 x 64, column-major ld 128); V[r, l] = Vc[l][r - l] for 0 <= r - l < 64
-  double* vt = sb + SL.vt2 + dia * kDiaSize;
-  {
-    const int r = tid & 127, half = tid >> 7;
-    for (int c = half * 32; c < half * 32 + 32; ++c) {
-      double s = 0.0;
-      const int l0 = std::max(0, r - (kB - 1)), l1 = std::min(c, r);
-      for (int l = l0; l <= l1; ++l) s += Vc[l * LD + r - l] * GT[l * LD + c];
-      vt[(size_t)c * kDiaLd + r] = s;
-    }
-  }
-}
-
-// ================================================================================================================
-// Z <- Q2 Z, fused.  The columns of Z are independent, so one workgroup takes kNc = 32 columns through ALL diamonds
-// (sweep groups last to first, chase positions first to last) with no synchronisation between workgroups:
-//   W1^T (32 x 64) = Z^T (32 x 128) VD (128 x 64)           A operand: LDS copy of the Z window, B: VD from L2
-//   Z^T (32 x 128) -= W1^T (32 x 64) VT^T (64 x 128)          A operand: W1 via LDS, B: VT from L2
-// The 128-row window of Z stays in registers as MFMA accumulators (wave w owns rows 16w.. of each 64-row half); going
-// from one chase position to the next, the lower half becomes the upper half (register rename), 64 finished rows are
-// stored and 64 new rows are loaded: Z is read once and written once per sweep group.
-constexpr int kNc = 32;
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256, 2) void k_bt2_fused(const double* __restrict__ sb_all, SbLayout SL,
-                                                      const int* __restrict__ dia_off, double* __restrict__ z_all,
-                                                      long long stride_z, int ncols, int batch, int xcd_map) {
-  constexpr int LDH = kB + 2;      // Z window copy: [col][row in half], 66: conflict-free A-operand reads
-  constexpr int LDW = kNc + 16;    // W1 copy: [sweep][col]
-  __shared__ double Zs[2][kNc * LDH];
-  __shared__ double W1s[kG * LDW];
-  const int n = SL.n;
-  // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and every workgroup
-  // streams all diamonds of its matrix through that L2.  With xcd_map the 1-D grid is decoded so that all column
-  // chunks of a matrix run on the same XCD (matrix b on XCD b mod 8): a diamond is then fetched over the fabric
-  // once per XCD-round instead of once per XCD and drifts less out of the L2.
-  int mat, chunk;
-  if (xcd_map) {
-    const int nchunk = (ncols + kNc - 1) / kNc;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    mat = xcd + 8 * (slot / nchunk);
-    chunk = slot % nchunk;
-    if (mat >= batch) return;
-  } else {
-    mat = blockIdx.y;
-    chunk = blockIdx.x;
-  }
-  const double* sb = sb_all + (size_t)mat * SL.slab;
-  double* Z = z_all + (size_t)mat * stride_z;
-  const int j0 = chunk * kNc;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int fr = lane & 15, fk = lane >> 4;
-
-  // accumulators: zt[h][ni][r] <-> Z(row = win + 64 h + 16 w + fr, col = j0 + 16 ni + fk + 4 r)
-  d4 zt[2][2];
-  double b1[20], b2[2][16];
-
-  auto load_half = [&](int h, int row0) {   // rows row0 + 16 w + fr
-    const int row = row0 + 16 * w + fr;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = j0 + 16 * ni + fk + 4 * r;
-        // unconditional load from a clamped address, masked afterwards
-        const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
-        zt[h][ni][r] = (row < n && col < ncols) ? v : 0.0;
-      }
-  };
-  auto store_half = [&](int h, int row0) {
-    const int row = row0 + 16 * w + fr;
-    if (row >= n) return;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = j0 + 16 * ni + fk + 4 * r;
-        if (col < ncols) Z[(size_t)col * n + row] = zt[h][ni][r];
-      }
-  };
-  auto copy_half_to_lds = [&](int h, int phys) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Zs[phys][(16 * ni + fk + 4 * r) * LDH + 16 * w + fr] = zt[h][ni][r];
-  };
-  // The diamond is a parallelogram: sweep c is non-zero in rows c .. c + 63 only.  Wave w (sweeps 16 w .. 16 w + 15)
-  // therefore only needs rows 16 w .. 16 w + 79 of VD in the first product (20 of the 32 k-steps), and in the second
-  // product the rows 64 + 16 w .. of VT are zero for sweeps < 16 w (VT[r, c] = sum_l V[r, l] T[l, c], l >= r - 63).
-  auto fetch_b1 = [&](size_t dia) {   // VD[row 16 w + 4 kk + fk][sweep 16 w + fr], kk < 20
-    const double* vd = sb + SL.vd + dia * kDiaSize + 16 * w + fr + (size_t)(16 * w + fk) * kG;
-#pragma unroll
-    for (int kk = 0; kk < 20; ++kk) b1[kk] = vd[(size_t)kk * 4 * kG];
-  };
-  auto fetch_b2 = [&](size_t dia) {   // VT[row 64 h + 16 w + fr][sweep 4 kk + fk]
-    const double* vt = sb + SL.vt2 + dia * kDiaSize + 16 * w + fr + (size_t)fk * kDiaLd;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) b2[h][kk] = vt[(size_t)kk * 4 * kDiaLd + 64 * h];
-  };
-
-  for (int S = SL.ngroups - 1; S >= 0; --S) {
-    const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
-    int win = S * kG + 1;          // first row of the window
-    int par = 0;                   // physical LDS buffer of the window's first half
-    load_half(0, win);
-    load_half(1, win + 64);
-    fetch_b1((size_t)d0);
-    fetch_b2((size_t)d0);
-    copy_half_to_lds(0, 0);
-    copy_half_to_lds(1, 1);
-    for (int k = 0; k < nk; ++k) {
-      __syncthreads();   // window copy complete
-      // ---- W1^T = Z^T VD
-      d4 c1[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
-#pragma unroll
-      for (int kk = 0; kk < 20; ++kk) {
-        const int kr = 4 * w + kk;                 // k-step (4 rows each) within the 128-row window
-        const double* zs = Zs[(kr >> 4) ^ par];
-        const int rr = (kr & 15) * 4 + fk;
-        const double a0 = zs[fr * LDH + rr], a1 = zs[(16 + fr) * LDH + rr];
-        c1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1[kk], c1[0], 0, 0, 0);
-        c1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[kk], c1[1], 0, 0, 0);
-      }
-      if (k + 1 < nk) fetch_b1((size_t)d0 + k + 1);   // consumed: refill for the next diamond
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) W1s[(16 * w + fr) * LDW + 16 * ni + fk + 4 * r] = -c1[ni][r];
-      __syncthreads();   // W1 complete; nobody reads the window copy any more
-      // the 64 rows that enter the window next are not touched by this diamond: fetch them now, behind the MFMAs
-      d4 zn[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
-      if (k + 1 < nk) {
-        const int row = win + 128 + 16 * w + fr;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int col = j0 + 16 * ni + fk + 4 * r;
-            const double v = Z[(size_t)std::min(col, ncols - 1) * n + std::min(row, n - 1)];
-            zn[ni][r] = (row < n && col < ncols) ? v : 0.0;
-          }
-      }
-      // ---- Z^T -= W1^T VT^T
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const double a0 = W1s[(4 * kk + fk) * LDW + fr], a1 = W1s[(4 * kk + fk) * LDW + 16 + fr];
-        zt[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[0][kk], zt[0][0], 0, 0, 0);
-        zt[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[0][kk], zt[0][1], 0, 0, 0);
-        if (kk >= 4 * w) {   // wave-uniform
-          zt[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2[1][kk], zt[1][0], 0, 0, 0);
-          zt[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2[1][kk], zt[1][1], 0, 0, 0);
-        }
-      }
-      if (k + 1 < nk) fetch_b2((size_t)d0 + k + 1);
-      // ---- slide: the first half is finished
-      store_half(0, win);
-      if (k + 1 < nk) {
-        zt[0][0] = zt[1][0];
-        zt[0][1] = zt[1][1];
-        copy_half_to_lds(0, par ^ 1);       // the old second half (updated) stays where it is, as the new first half
-        win += 64;
-        zt[1][0] = zn[0];
-        zt[1][1] = zn[1];
-        copy_half_to_lds(1, par);           // new rows go where the finished half was
-        par ^= 1;
-      } else {
-        store_half(1, win + 64);
-      }
-    }
-    __syncthreads();   // the next group rewrites both window buffers
-  }
-}
-
-
-// ================================================================================================================
-// Z <- Q2 Z, second generation (k_dia_tfactor2 + k_bt2_apply; tools/models/bt2_model.py is their NumPy specification).
+// Z <- Q2 Z (k_dia_tfactor2 + k_bt2_apply; tools/models/bt2_model.py is their NumPy specification).
 //
-// The f64 matrix pipe issues one 16x16x4 MFMA per 64 cycles (profiles/r02_probe_clock.txt); k_bt2_fused kept it 43 % busy
-// because every wave fetched its own B operands from L2 (52 doubles per lane and diamond for 184 MFMAs).  Here
+// The f64 matrix pipe issues one 16x16x4 MFMA per 64 cycles (profiles/r02_probe_clock.txt).  The columns of Z are
+// independent, so ONE launch lets every workgroup take 16 NW columns through ALL diamonds in order (sweep groups last to
+// first, chase positions first to last) with no synchronisation between workgroups:
 //   * the 128-row window of Z lives in the accumulators as Z itself (rows x columns), split over the waves by COLUMNS:
 //     a wave owns 16 columns x 128 rows = 8 accumulator tiles.  An accumulator register of this MFMA has exactly the lane
-//     layout of a B operand (k = lane >> 4 <-> tile row 4 r + k, j = lane & 15), so  W1 = V^T Z  takes its B operands
-//     straight from the window registers and  Z -= (V T) W1  takes them straight from the W1 accumulators: no LDS
-//     round trip for Z or W1, no synchronisation between the two products;
+//     layout of a B operand (k = lane >> 4 <-> tile row 4 r + k, j = lane & 15), so  W = V^T Z  takes its B operands
+//     straight from the window registers and  Z -= (V T) W  takes them straight from the W accumulators: no LDS
+//     round trip for Z or W; going from one chase position to the next the window slides by 64 rows (64 finished rows
+//     are stored, 64 new ones loaded): Z is read and written once per sweep group;
+//   * a diamond (64 sweeps at one chase position) is applied as FOUR compact-WY blocks of 16 sweeps ("minis", sweep tile
+//     st = 3, 2, 1, 0: Q = Q_0 Q_1 Q_2 Q_3, the last acts first).  The reflectors of a mini span rows 16 st .. 16 st + 78
+//     = 5 row tiles for V^T Z and for (V T) W alike: 4 x (20 + 20) = 160 MFMAs per diamond and 16 columns, 1.25 x the
+//     algorithmic flops.  (Round 2 applied all 64 sweeps as one block: 80 + 104 MFMAs = 1.44 x, because V T of a
+//     64-sweep block is a trapezoid rather than a parallelogram.)
 //   * the A operands (V^T and -(V T)) are the same for every wave and every column chunk: k_dia_tfactor2 writes them
-//     once per diamond as ready-made MFMA fragments (512 B = one wave-wide ds_read_b64 each) in the order the products
-//     consume them, structural zeros skipped: 80 fragments for V^T (sweep tile st meets row tiles st .. st + 4 only) and
-//     104 for -(V T) (row tile rt meets sweep tiles >= rt - 4 only) = 92 KB per diamond;
-//   * a workgroup of NW = 8 waves (128 columns) streams the fragments of the next product into LDS with LDS-DMA
-//     (global_load_lds_dwordx4, no staging registers) while the current product runs: region A (V^T fragments) is refilled
-//     during product 2, region B during product 1; two barriers per diamond.  A diamond is read from L2 / HBM once per
-//     128 columns instead of once per 32.
+//     once per diamond as ready-made MFMA fragments (512 B = one wave-wide ds_read_b64 each) in exactly the order the
+//     products consume them, 160 per diamond = 80 KB;
+//   * a workgroup streams the fragments into a ring of three half-diamond buffers (40 KB each) with LDS-DMA
+//     (global_load_lds_dwordx4, no staging registers), two halves ahead of the MFMAs; one barrier per half.
 #ifndef BT2_DBG
 #define BT2_DBG 0
 #endif
@@ -1245,28 +1022,19 @@ __device__ unsigned long long g_bt2_stamps[64 * 8 * 9];
 #define BT2_STAMP(i)
 #define BT2_STAMP_WRITE
 #endif
-constexpr int kF1 = 80, kF2 = 104;                 // fragments per diamond: product 1 / product 2
-constexpr int kFragDoubles = (kF1 + kF2) * 64;     // 11776 doubles = 92 KB
-// product 1: sweep tile st meets row tiles rt = st .. st + 4 (the reflectors' parallelogram), k-steps r = 0..3 each.  Issue
-// order: f = 4 i + st with i = 4 (rt - st) + r, i.e. the four accumulators W1[st] take turns; Z tile rt register r is
-// the B operand.
-__host__ __device__ constexpr int p1_index(int rt, int r, int st) { return 4 * (4 * (rt - st) + r) + st; }
-// product 2, issue order (st, r, rt): W1 tile st register r is the B operand; row tiles rt = 0 .. 4 + st
-__host__ __device__ constexpr int p2_base(int st) { return 4 * (5 * st + st * (st - 1) / 2); }
-__host__ __device__ constexpr int p2_index(int st, int r, int rt) { return p2_base(st) + r * (5 + st) + rt; }
-static_assert(p1_index(7, 3, 3) == kF1 - 1 && p2_base(4) == kF2, "fragment counts");
-// fragment index = issue index; the inverse maps (constant-folded in the unrolled products)
-struct P1Step { int rt, r, st; };
-__host__ __device__ constexpr P1Step p1_decode(int f) { return P1Step{(f & 3) + (f >> 4), (f >> 2) & 3, f & 3}; }
-struct P2Step { int st, r, rt; };
-__host__ __device__ constexpr P2Step p2_decode(int f) {
-  int st = 0;
-  while (st < 3 && f >= p2_base(st + 1)) ++st;
-  const int rem = f - p2_base(st);
-  return P2Step{st, rem / (5 + st), rem % (5 + st)};
-}
-static_assert(p1_index(p1_decode(37).rt, p1_decode(37).r, p1_decode(37).st) == 37, "p1 decode");
-static_assert(p2_index(p2_decode(71).st, p2_decode(71).r, p2_decode(71).rt) == 71, "p2 decode");
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int kMini = 16;                          // sweeps per compact-WY block
+constexpr int kMiniFrags = 40;                     // fragments per mini: 20 of V^T, 20 of -(V T)
+constexpr int kDiaFrags = 4 * kMiniFrags;          // 160 per diamond
+constexpr int kHalfFrags = 2 * kMiniFrags;         // a half-diamond (two minis) is the unit of the LDS ring
+constexpr int kHalfDoubles = kHalfFrags * 64;      // 5120 doubles = 40 KB
+constexpr int kFragDoubles = kDiaFrags * 64;       // 10240 doubles = 80 KB
+// Fragment index inside a diamond = issue index: minis in the order st = 3, 2, 1, 0; inside a mini first the 20 steps
+// of W = V_st^T Z (j = 4 (rt - st) + r: Z tile rt register r is the B operand), then the 20 of Z -= (V_st T_st) W
+// (j = 5 r + (rt - st): W register r is the B operand, the five row tiles take turns).
+__host__ __device__ constexpr int mf_p1(int st, int rt, int r) { return (3 - st) * kMiniFrags + 4 * (rt - st) + r; }
+__host__ __device__ constexpr int mf_p2(int st, int rt, int r) { return (3 - st) * kMiniFrags + 20 + 5 * r + (rt - st); }
+static_assert(mf_p2(0, 4, 3) == kDiaFrags - 1 && mf_p1(3, 3, 0) == 0, "fragment order");
 
 typedef const double __attribute__((address_space(1)))* zptr_c;   // global_load / global_store, never flat
 typedef double __attribute__((address_space(1)))* zptr;
@@ -1284,18 +1052,15 @@ __device__ __forceinline__ d4 mma_range(d4 acc, int k4_lo, int k4_hi, int fr, in
   return acc;
 }
 
-// Per diamond: T = (diag(1 / tau) + striu(V^T V))^-1 (the dlarft recurrence is the back substitution for this inverse;
-// reflectors with tau = 0 are decoupled), then the fragments of V^T and -(V T)^T.  All products on the matrix cores:
-//   Gram (upper tiles, rows where both reflector groups are non-zero), the inverse blocked 16 -> 32 -> 64
-//   (diagonal 16 x 16 blocks by back substitution, one column per lane; off-diagonal blocks X12 = -X11 U12 X22),
-//   and (V T)^T tile by tile - computed transposed because an accumulator register of the transposed tile IS the
-//   fragment (same lane, same order), so it is stored with one coalesced 512-byte write.
+// Per diamond and mini: T = (diag(1 / tau) + striu(V^T V))^-1 of the mini's 16 reflectors (the dlarft recurrence is the
+// back substitution for this inverse; reflectors with tau = 0 are decoupled), then the fragments of V^T and -(V T)^T.
+// Gram blocks and (V T)^T on the matrix cores; (V T)^T is computed transposed because an accumulator register of the
+// transposed tile IS the fragment (same lane, same order), so it is stored with one coalesced 512-byte write.
 __global__ __launch_bounds__(256) void k_dia_tfactor2(double* __restrict__ sb_all, SbLayout SL, int dia0) {
   constexpr int LD = kG + 1;
-  __shared__ double Vc[kG * LD];     // Vc[c * LD + i] = V[c + i, c]
-  __shared__ double Us[kG * LD];     // U[a * LD + b]
-  __shared__ double Ts[kG * LD];     // T[a * LD + b]
-  __shared__ double Ps[32 * 33];
+  __shared__ double Vc[kG * LD];          // Vc[c * LD + i] = V[c + i, c]
+  __shared__ double Us[4][kMini * 17];    // per mini: U[a * 17 + b], a <= b
+  __shared__ double Ts[4][kMini * 17];    // per mini: T[a * 17 + b]
   __shared__ double tau_s[kG];
   double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
   const size_t dia = (size_t)dia0 + blockIdx.x;
@@ -1308,93 +1073,58 @@ __global__ __launch_bounds__(256) void k_dia_tfactor2(double* __restrict__ sb_al
     const int c = tid & 63, q = tid >> 6;   // lanes along the sweeps (contiguous in memory)
     for (int i = q; i < kB; i += 4) Vc[c * LD + i] = vd[(size_t)(c + i) * kG + c];
     if (tid < kG) tau_s[tid] = tau[tid];
-    for (int idx = tid; idx < kG * LD; idx += 256) { Us[idx] = 0.0; Ts[idx] = 0.0; }
   }
   __syncthreads();
   auto V = [&](int row, int c) -> double {
     const int i = row - c;
     return (unsigned)i < (unsigned)kB ? Vc[c * LD + i] : 0.0;
   };
-  // ---- U: strictly upper part of the Gram matrix, 1 / tau on the diagonal
-  for (int t = w; t < 10; t += 4) {
-    const int ta = t < 4 ? 0 : (t < 7 ? 1 : (t < 9 ? 2 : 3));
-    const int tb = t < 4 ? t : (t < 7 ? t - 3 : (t < 9 ? t - 5 : 3));
-    d4 g = mma_range(d4{0, 0, 0, 0}, 4 * tb, 4 * ta + 20, fr, fk,
-                     [&](int i, int k) { return V(k, 16 * ta + i); }, [&](int k, int j) { return V(k, 16 * tb + j); });
+  // ---- U of mini st = w: strictly upper part of its Gram block (rows 16 st .. 16 st + 78), 1 / tau on the diagonal
+  {
+    const int st = w;
+    const d4 g = mma_range(d4{0, 0, 0, 0}, 4 * st, 4 * st + 20, fr, fk,
+                           [&](int i, int k) { return V(k, 16 * st + i); }, [&](int k, int j) { return V(k, 16 * st + j); });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int a = 16 * ta + 4 * r + fk, b = 16 * tb + fr;
-      if (a < b) Us[a * LD + b] = (tau_s[a] != 0.0 && tau_s[b] != 0.0) ? g[r] : 0.0;
+      const int a = 4 * r + fk, b = fr;
+      const double ta = tau_s[16 * st + a], tb = tau_s[16 * st + b];
+      double u = 0.0;
+      if (a < b) u = (ta != 0.0 && tb != 0.0) ? g[r] : 0.0;
+      else if (a == b) u = ta != 0.0 ? 1.0 / ta : 1.0;
+      Us[st][a * 17 + b] = u;
     }
   }
-  if (tid < kG) Us[tid * LD + tid] = tau_s[tid] != 0.0 ? 1.0 / tau_s[tid] : 1.0;
   __syncthreads();
-  // ---- diagonal blocks: lane (b, j) solves U_bb x = e_j
+  // ---- lane (st, j) of the first wave solves U_st x = e_j by back substitution
   if (w == 0) {
-    const int b = lane >> 4, j = lane & 15;
-    const double* Ub = Us + (16 * b) * LD + 16 * b;
+    const int st = lane >> 4, j = lane & 15;
+    const double* Ub = Us[st];
     double x[16];
 #pragma unroll
     for (int i = 15; i >= 0; --i) {
       double s = i == j ? 1.0 : 0.0;
 #pragma unroll
-      for (int l = i + 1; l < 16; ++l) s -= Ub[i * LD + l] * x[l];
-      x[i] = i <= j ? s / Ub[i * LD + i] : 0.0;
+      for (int l = i + 1; l < 16; ++l) s -= Ub[i * 17 + l] * x[l];
+      x[i] = i <= j ? s / Ub[i * 17 + i] : 0.0;
     }
+    if (tau_s[16 * st + j] == 0.0) x[j] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Ts[(16 * b + i) * LD + 16 * b + j] = x[i];
+    for (int i = 0; i < 16; ++i) Ts[st][i * 17 + j] = x[i];
   }
   __syncthreads();
-  // ---- level 1: blocks (0,1) and (2,3):  X = -T_aa (U_ac T_cc)
-  if (w < 2) {
-    const int lo = 32 * w;
-    d4 p = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Us[(lo + i) * LD + lo + 16 + k]; },
-                     [&](int k, int j) { return Ts[(lo + 16 + k) * LD + lo + 16 + j]; });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Ps[(16 * w + 4 * r + fk) * 33 + fr] = p[r];
+  // ---- fragments of V^T: lane l holds V[16 rt + 4 r + (l >> 4)][16 st + (l & 15)]
+  for (int idx = tid; idx < 4 * 20 * 64; idx += 256) {
+    const int l = idx & 63, f = idx >> 6;
+    const int st = f / 20, j = f % 20, rt = st + j / 4, r = j % 4;
+    frag[(size_t)mf_p1(st, rt, r) * 64 + l] = V(16 * rt + 4 * r + (l >> 4), 16 * st + (l & 15));
   }
-  __syncthreads();
-  if (w < 2) {
-    const int lo = 32 * w;
-    d4 x = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Ts[(lo + i) * LD + lo + k]; },
-                     [&](int k, int j) { return Ps[(16 * w + k) * 33 + j]; });
+  // ---- fragments of -(V T): tile (st, rt) transposed,  D'[sweep i][row j] = sum_l T_st[l][i] V[16 rt + j][16 st + l]
+  for (int q = w; q < 20; q += 4) {
+    const int st = q / 5, rt = st + q % 5;
+    const d4 d = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Ts[st][k * 17 + i]; },
+                           [&](int k, int j) { return V(16 * rt + j, 16 * st + k); });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ts[(lo + 4 * r + fk) * LD + lo + 16 + fr] = -x[r];
-  }
-  __syncthreads();
-  // ---- level 2: the 32 x 32 block (rows 0..31, columns 32..63), one 16 x 16 tile per wave
-  {
-    const int ti = w & 1, tj = w >> 1;
-    d4 p = mma_range(d4{0, 0, 0, 0}, 0, 8, fr, fk, [&](int i, int k) { return Us[(16 * ti + i) * LD + 32 + k]; },
-                     [&](int k, int j) { return Ts[(32 + k) * LD + 32 + 16 * tj + j]; });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Ps[(16 * ti + 4 * r + fk) * 33 + 16 * tj + fr] = p[r];
-    __syncthreads();
-    d4 x = mma_range(d4{0, 0, 0, 0}, 0, 8, fr, fk, [&](int i, int k) { return Ts[(16 * ti + i) * LD + k]; },
-                     [&](int k, int j) { return Ps[k * 33 + 16 * tj + j]; });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Ts[(16 * ti + 4 * r + fk) * LD + 32 + 16 * tj + fr] = -x[r];
-  }
-  __syncthreads();
-  if (tid < kG && tau_s[tid] == 0.0) Ts[tid * LD + tid] = 0.0;
-  __syncthreads();
-  // ---- fragments of V^T: frag1[f][l] = V[16 rt + 4 r + (l >> 4)][16 st + (l & 15)]
-  for (int idx = tid; idx < kF1 * 64; idx += 256) {
-    const int f = idx >> 6, l = idx & 63;
-    const P1Step d = p1_decode(f);
-    frag[idx] = V(16 * d.rt + 4 * d.r + (l >> 4), 16 * d.st + (l & 15));
-  }
-  // ---- fragments of -(V T): tile (st, rt) transposed,  D'[sweep i][row j] = sum_l T[l][16 st + i] V[16 rt + j][l]
-  double* frag2 = frag + kF1 * 64;
-  for (int q = w; q < 26; q += 4) {
-    const int st = q < 5 ? 0 : (q < 11 ? 1 : (q < 18 ? 2 : 3));
-    const int rt = q - (st == 0 ? 0 : (st == 1 ? 5 : (st == 2 ? 11 : 18)));
-    const int k4_lo = 4 * rt > 16 ? 4 * rt - 16 : 0;
-    const int k4_hi = 4 * st + 4 < 4 * rt + 4 ? 4 * st + 4 : 4 * rt + 4;
-    d4 d = mma_range(d4{0, 0, 0, 0}, k4_lo, k4_hi, fr, fk, [&](int i, int k) { return Ts[k * LD + 16 * st + i]; },
-                     [&](int k, int j) { return V(16 * rt + j, k); });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) frag2[(size_t)p2_index(st, r, rt) * 64 + lane] = -d[r];
+    for (int r = 0; r < 4; ++r) frag[(size_t)mf_p2(st, rt, r) * 64 + lane] = -d[r];
   }
 }
 
@@ -1403,11 +1133,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
                                                           const int* __restrict__ dia_off, double* __restrict__ z_all,
                                                           long long stride_z, int ncols, int batch, int xcd_map) {
   constexpr int dbg = BT2_DBG;   // ablation builds only (tools/ablate_bt2.sh): 1 no fragment DMA, 2 no Z traffic, 4 no MFMAs
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // regions A0 | A1 (kF1 * 64 each) | B (kF2 * 64)
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // ring of 3 half-diamond buffers | transposition tiles
   const int n = SL.n;
   constexpr int kCols = 16 * NW;
   int mat, chunk;
-  if (xcd_map) {   // all column chunks of a matrix on one XCD (see k_bt2_fused)
+  if (xcd_map) {   // all column chunks of a matrix on one XCD: they stream the same fragments through one L2
     const int nchunk = (ncols + kCols - 1) / kCols;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     mat = xcd + 8 * (slot / nchunk);
@@ -1422,7 +1152,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   const int fr = lane & 15, fk = lane >> 4;
   const int col = chunk * kCols + 16 * w + fr;          // this lane's column in the accumulator layout
   const double col_mask = col < ncols ? 1.0 : 0.0;
-  const double* ldsB = lds + 2 * kF1 * 64 + lane;
 
   // ---- Z <-> accumulator tiles.  In the accumulator layout a lane owns (row 4 r + fk, column fr): a global access in
   // that shape is 16 columns x 32 bytes per instruction, which the memory path serves at ~3 TB/s (measured: the Z
@@ -1431,7 +1160,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   // 8 full 128-byte column segments per instruction - and each 16 x 16 tile is transposed through a wave-private LDS
   // tile [column][18] on its way to / from the accumulator layout (LDS executes a wave's accesses in order: no waits).
   constexpr int kStg = 16 * 18;
-  double* stg = lds + (2 * kF1 + kF2) * 64 + w * kStg;
+  double* stg = lds + 3 * kHalfDoubles + w * kStg;
   const int gc = lane >> 3, gr = (lane & 7) * 2;
   const int col_a = chunk * kCols + 16 * w + gc, col_b = col_a + 8;
   double* z_mat = z_all + (size_t)mat * stride_z;
@@ -1492,29 +1221,26 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     tile_to_rows(t, v);
     store_rows(v, row0);
   };
-  // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a fragment block; the waves share the instructions.
+  // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a half-diamond; the waves share the instructions.
   // Issued from inline asm: hipcc then keeps no scoreboard entry for them (with the builtin it guards later LDS reads
   // and register reuse with vmcnt(0), i.e. waits for the DMA it has just issued); their completion is counted by hand:
   // every wait for them below is an explicit vmcnt(0).  M0 (the LDS destination base) is saved and restored.
   const unsigned lds_base = (unsigned)(size_t)(lvoid)lds;
-  // this wave's j-th instruction of a block of n_instr (the waves share the instructions round robin)
-  auto dma_one = [&](const double* src, int lds_off_doubles, int n_instr, int j) {
+  constexpr int kDmaInstr = kHalfDoubles * 8 / 1024;          // 40 per half
+  constexpr int kDmaPer = (kDmaInstr + NW - 1) / NW;          // per wave: 5 (8 waves) or 10 (4 waves)
+  // this wave's j-th instruction of the half at `src` into ring slot `slot`
+  auto dma_one = [&](const double* src, int slot, int j) {
     const int q = w + NW * j;
-    if (q < n_instr) {
+    if (q < kDmaInstr) {
       unsigned keep;
       const char* gq = (const char*)src + lane * 16 + q * 1024;
-      const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)lds_off_doubles * 8u + (unsigned)q * 1024u);
+      const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * kHalfDoubles) * 8u + (unsigned)q * 1024u);
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(gq), "s"(lq)
                    : "memory");
     }
   };
-  auto dma = [&](const double* src, int lds_off_doubles, int n_instr) {
-    for (int j = 0; j * NW < n_instr; ++j) dma_one(src, lds_off_doubles, n_instr, j);
-  };
-  constexpr int kBper = (kF2 / 2 + NW - 1) / NW;   // DMA instructions per wave: region B (7 or 13)
-  constexpr int kAper = (kF1 / 2 + NW - 1) / NW;   //                              region A (5 or 10)
   auto wait_vm0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto barrier = [&]() {
     asm volatile("" ::: "memory");
@@ -1523,17 +1249,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   };
 
   d4 zt[8];
-  // the 64 rows finished at the last slide: stored one diamond later, behind the MFMAs of product 2 (the 8-wave kernel
-  // only: with 4 waves the twice as many DMA instructions per wave leave no registers for it, the rows go out at the slide)
-  constexpr bool kDefer = NW == 8;
-  d4 zfin[kDefer ? 4 : 1];
+  // the 64 rows finished at the last slide: stored one diamond later, behind the MFMAs of the next diamond's first half
+  d4 zfin[4];
   int fin_row = 0;
   bool have_fin = false;
   BT2_STAMP_DECL
   for (int S = SL.ngroups - 1; S >= 0; --S) {
     const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
+    const int nh = 2 * nk;                                    // halves of this group, streamed back to back
     int win = S * kG + 1;
-    const double* fcur = sb + SL.frag + (size_t)d0 * kFragDoubles;
+    const double* fgrp = sb + SL.frag + (size_t)d0 * kFragDoubles;
     {
       Raw raw[8];
 #pragma unroll
@@ -1541,107 +1266,91 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) scatter_tile(zt[rt], raw[rt], win + 16 * rt);
     }
-    barrier();                       // every wave has left the previous group's products: all regions are free
-    dma(fcur, 0, kF1 / 2);           // region A0 <- first diamond
+    barrier();                       // every wave has left the previous group: the whole ring is free
+    if (!(dbg & 1)) {
+      for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp, 0, j);
+      for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp + kHalfDoubles, 1, j);
+    }
     wait_vm0();
     __builtin_amdgcn_sched_barrier(0);
-    for (int k = 0; k < nk; ++k, fcur += kFragDoubles) {
+    int slot = 0;                    // ring slot of the half about to run
+    for (int k = 0; k < nk; ++k) {
       const bool more = k + 1 < nk;
-      const double* ldsA = lds + (k & 1) * (kF1 * 64) + lane;
-      BT2_STAMP(0)
-      barrier();                     // X1: region A[k & 1] complete in LDS; every wave is done with B and with A[(k + 1) & 1]
-      BT2_STAMP(1)
-      // ---- W1 = V^T Z.  Fragments in groups of 8: the next group is read from LDS while the MFMAs of the current one
-      // issue.  Everything else a diamond needs is issued in the shadow of these MFMA runs, a little per group (measured
-      // with in-kernel stamps, profiles/r02_bt2_stamps.txt: issued in bursts in front of the products and at the slide,
-      // the LDS-DMAs and the store path cost 8k of the 34k cycles of a diamond): here the DMA of this diamond's -(V T)
-      // fragments into region B.
-      d4 w1[4] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
-      {
+      Raw zn[4], fin_rows;
+#pragma unroll
+      for (int H = 0; H < 2; ++H) {
+        const int q = 2 * k + H;                               // half index inside the group
+        const double* ldsH = lds + slot * kHalfDoubles + lane;
+        const int slot_pre = slot == 0 ? 2 : slot - 1;         // ring slot of half q + 2 (= the one half q - 1 has left)
+        const double* src_pre = fgrp + (size_t)(q + 2) * kHalfDoubles;
+        const bool pre = q + 2 < nh;
+        BT2_STAMP(H == 0 ? 0 : 3)
+        barrier();                   // half q complete in LDS (every wave waited for its own part); half q - 1 finished
+        BT2_STAMP(H == 0 ? 1 : 4)
+        // ---- 80 MFMAs: minis st = 3 - 2 H and 2 - 2 H.  Fragments in groups of 8: the next group is read from LDS while
+        // the MFMAs of the current one issue.  Everything else is issued in the shadow of these MFMA runs, a little per
+        // group: the DMA of half q + 2, in the first half the store of the rows finished at the last slide (LDS
+        // transposition one group, the global store the next), in the second half the loads of the 64 rows that enter
+        // the window at the slide (raw values, scattered and masked at the slide; issued and consumed in EVERY
+        // iteration - after the last diamond of a group they are not needed, the clamped addresses are still valid:
+        // hipcc's wait-count bookkeeping is not path sensitive, and loads that are only issued / consumed under `more`
+        // stay "maybe pending" around the loop, which costs a vmcnt(0) wherever their registers are reused).
+        d4 wa = d4{0, 0, 0, 0}, wb = d4{0, 0, 0, 0}, ww = d4{0, 0, 0, 0};
         double fa[2][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fa[0][j] = ldsA[j * 64];
+        for (int j = 0; j < 8; ++j) fa[0][j] = ldsH[j * 64];
 #pragma unroll
-        for (int g = 0; g < ((dbg & 4) ? 1 : kF1 / 8); ++g) {
-          if (g + 1 < kF1 / 8) {
+        for (int g = 0; g < ((dbg & 4) ? 1 : kHalfFrags / 8); ++g) {
+          if (g + 1 < kHalfFrags / 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsA[((g + 1) * 8 + j) * 64];
+            for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsH[((g + 1) * 8 + j) * 64];
           }
-          if (g < 4 && !(dbg & 1)) {
+          if (g < 5 && pre && !(dbg & 1)) {
 #pragma unroll
-            for (int j = g * ((kBper + 3) / 4); j < (g + 1) * ((kBper + 3) / 4) && j < kBper; ++j)
-              dma_one(fcur + kF1 * 64, 2 * kF1 * 64, kF2 / 2, j);
+            for (int j = g * ((kDmaPer + 4) / 5); j < (g + 1) * ((kDmaPer + 4) / 5) && j < kDmaPer; ++j)
+              dma_one(src_pre, slot_pre, j);
+          }
+          if (H == 0 && g >= 1 && g <= 5 && have_fin && !(dbg & 2)) {
+            if (g >= 2) store_rows(fin_rows, fin_row + 16 * (g - 2));
+            if (g <= 4) tile_to_rows(zfin[g - 1], fin_rows);
+          }
+          if (H == 1 && g < 2 && !(dbg & 2)) {
+            load_raw(zn[2 * g], win + 128 + 32 * g);
+            load_raw(zn[2 * g + 1], win + 128 + 32 * g + 16);
           }
           __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g + 1 in front of the MFMAs of group g
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const P1Step d = p1_decode(g * 8 + j);
-            w1[d.st] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[g & 1][j], zt[d.rt][d.r], w1[d.st], 0, 0, 0);
+            const int f = 8 * g + j;
+            const int st = 3 - 2 * H - f / kMiniFrags, p = f % kMiniFrags;
+            const double a = fa[g & 1][j];
+            if (p < 20) {            // W += V^T Z: two accumulators take turns
+              const int rt = st + p / 4, r = p % 4;
+              if (p == 0) wa = d4{0, 0, 0, 0};
+              if (p == 1) wb = d4{0, 0, 0, 0};
+              if (p & 1) wb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zt[rt][r], wb, 0, 0, 0);
+              else wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zt[rt][r], wa, 0, 0, 0);
+            } else {                 // Z -= (V T) W: the five row tiles take turns
+              if (p == 20) ww = wa + wb;
+              const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
+              zt[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ww[r], zt[rt], 0, 0, 0);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      BT2_STAMP(2)
-      wait_vm0();                    // X2: this wave's part of region B (nothing else of this wave is in flight)
-      BT2_STAMP(3)
-      barrier();
-      BT2_STAMP(4)
-      // ---- Z -= (V T) W1.  In the shadow of its MFMAs: the loads of the 64 rows that enter the window at the slide
-      // (raw values, scattered and masked at the slide; issued and consumed in EVERY iteration - after the last diamond
-      // of a group they are not needed, the clamped addresses are still valid: hipcc's wait-count bookkeeping is not path
-      // sensitive, and loads that are only issued / consumed under `more` stay "maybe pending" around the loop, which
-      // costs a vmcnt(0) wherever their registers are reused), the DMA of the next diamond's V^T fragments into the other
-      // A region, and the store of the rows that were finished at the last slide (LDS transposition one group, the
-      // global store the next).
-      Raw zn[4], fin_rows;
-      {
-        double fb[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fb[0][j] = ldsB[j * 64];
-#pragma unroll
-        for (int g = 0; g < ((dbg & 4) ? 3 : kF2 / 8); ++g) {
-          if (g + 1 < kF2 / 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fb[(g + 1) & 1][j] = ldsB[((g + 1) * 8 + j) * 64];
-          }
-          if (g < 2 && !(dbg & 2)) {
-            load_raw(zn[2 * g], win + 128 + 32 * g);
-            load_raw(zn[2 * g + 1], win + 128 + 32 * g + 16);
-          }
-          if (g < 5 && more && !(dbg & 1)) {
-#pragma unroll
-            for (int j = g * ((kAper + 4) / 5); j < (g + 1) * ((kAper + 4) / 5) && j < kAper; ++j)
-              dma_one(fcur + kFragDoubles, ((k + 1) & 1) * (kF1 * 64), kF1 / 2, j);
-          }
-          if (kDefer && g >= 5 && g <= 9 && have_fin && !(dbg & 2)) {
-            if (g >= 6) store_rows(fin_rows, fin_row + 16 * (g - 6));
-            if (g <= 8) tile_to_rows(zfin[kDefer ? g - 5 : 0], fin_rows);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const P2Step d = p2_decode(g * 8 + j);
-            zt[d.rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[g & 1][j], w1[d.st][d.r], zt[d.rt], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        BT2_STAMP(H == 0 ? 2 : 5)
+        wait_vm0();                  // this wave's part of half q + 1 (issued one half ago) and of half q + 2, the stores
+        slot = slot == 2 ? 0 : slot + 1;
       }
       // ---- slide by 64 rows: the finished rows move to zfin, the window shifts, the new rows are scattered in (the
       // shift is done after the last diamond of a group as well: its result is not used, but the new rows' loads must
       // have their first use on every path, see above)
-      BT2_STAMP(5)
-      wait_vm0();                    // the new rows, this wave's part of the next A region, the deferred stores
       BT2_STAMP(6)
-      if (more && kDefer) {
+      if (more) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) zfin[kDefer ? t : 0] = zt[t];
+        for (int t = 0; t < 4; ++t) zfin[t] = zt[t];
         fin_row = win;
         have_fin = true;
-      } else if (more) {
-        if (!(dbg & 2)) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) store_tile(zt[t], win + 16 * t);
-        }
       } else {
         if (!(dbg & 2)) {
 #pragma unroll
@@ -1668,12 +1377,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 
 // ================================================================================================================
 // Layout
-// SPRINGCRAFT_BT2_OLD=1: the first-generation stage-2 back-transformation (k_dia_tfactor + k_bt2_fused), kept for A/B runs
-static bool bt2_old_path() {
-  static const bool old = getenv("SPRINGCRAFT_BT2_OLD") != nullptr;
-  return old;
-}
-
 size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   SbLayout L{};
   L.n = n;
@@ -1699,8 +1402,7 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   }
   L.ndia = ndia;
   L.vd = take(ndia * kDiaSize);
-  if (bt2_old_path()) L.vt2 = take(ndia * kDiaSize);
-  else L.frag = take(ndia * kFragDoubles);
+  L.frag = take(ndia * kFragDoubles);
   L.tau2 = take(ndia * kG);
   (void)ncols;
   L.slab = off;
@@ -2043,10 +1745,7 @@ int bt2_prepare(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     if (ph.first == "dia_tfactor") ph.second = 0.0;
   for (long long d0 = 0; d0 < SL.ndia; d0 += 32768) {
     const unsigned cnt = (unsigned)std::min<long long>(32768, SL.ndia - d0);
-    if (bt2_old_path())
-      hipLaunchKernelGGL(k_dia_tfactor, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
-    else
-      hipLaunchKernelGGL(k_dia_tfactor2, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
+    hipLaunchKernelGGL(k_dia_tfactor2, dim3(cnt, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, (int)d0);
   }
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
@@ -2063,25 +1762,15 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
-  if (bt2_old_path()) {
-    const int nchunk = (ncols + kNc - 1) / kNc;
-    if (batch >= 8) {
-      const int per_xcd = (batch + 7) / 8;   // matrices per XCD
-      hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)(8 * per_xcd * nchunk)), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
-                         d_z, stride_z, ncols, batch, 1);
-    } else {
-      hipLaunchKernelGGL(k_bt2_fused, dim3((unsigned)nchunk, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, d_dia_off,
-                         d_z, stride_z, ncols, batch, 0);
-    }
-  } else {
+  {
     // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
-    // regions A0 | A1 | B + one 16 x 18 transposition tile per wave
-    const size_t lds = sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18);
+    // ring of three half-diamond fragment buffers + one 16 x 18 transposition tile per wave
+    constexpr size_t lds = sizeof(double) * (3 * kHalfDoubles + 8 * 16 * 18);
     static const bool attr_set = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18)));
+                                (int)lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * (kFragDoubles + kF1 * 64 + 8 * 16 * 18)));
+                                (int)lds);
       return true;
     }();
     (void)attr_set;

@@ -24,8 +24,9 @@ buf = (C.c_ulonglong * (64 * 8 * 9))()
 rc = _hip.lib().sc_dbg_bt2_stamps(buf)
 a = np.array(buf, dtype=np.float64).reshape(64, 8, 9)
 print("rc", rc, "diamonds per wave", a[0, 0, 8])
-names = ["slide end -> X1 arrive (loop top)", "X1 barrier wait", "DMA + row-load issue + product 1", "X2 vmcnt wait",
-         "X2 barrier wait", "product 2", "slide vmcnt wait", "slide (stores, shift, scatter)"]
+names = ["slide end -> barrier 0 arrive (loop top)", "barrier 0 wait", "half 0: minis 3, 2 (+ DMA issue, deferred stores)",
+         "vmcnt wait after half 0", "barrier 1 wait", "half 1: minis 1, 0 (+ DMA issue, row loads)",
+         "vmcnt wait after half 1", "slide (shift, scatter)"]
 per = a[:, :, :8] / np.maximum(a[:, :, 8:9], 1)
 tot = per.sum(-1).mean()
 for i, nm in enumerate(names):
