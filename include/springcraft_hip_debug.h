@@ -42,8 +42,12 @@ int sc_dbg_gemm_trace(unsigned long long* out, int max_records, int* count, int 
 int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* band_out, double* d_out, double* e_out);
 
 /* Per-wave s_memtime segment sums of k_bt2_apply (library built with -DBT2_STAMPS; returns 1 otherwise):
- * out[64 workgroups][8 waves][8 sums + diamond count].  tools/bt2_stamps.py */
+ * out[64 workgroups][8 waves][16 sums + diamond count].  tools/bt2_stamps.py */
 int sc_dbg_bt2_stamps(unsigned long long* out);
+
+/* s_memtime in front of every MFMA of one diamond of k_bt2_apply (library built with -DBT2_TRACE; returns 1 otherwise):
+ * out[8 waves][2 halves][81].  tools/bt2_trace.py */
+int sc_dbg_bt2_trace(unsigned long long* out);
 
 /* s_memtime sums of k_bulge_step over all tasks since the last call (library built with -DBULGE_STAMPS; returns 1
  * otherwise): out6 = {cycles from task start until the off-diagonal block E is in LDS, until E is stored [both: tasks

@@ -24,6 +24,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
           "-I", join(REPO, "include")] + os.environ.get("SC_EXTRA_HIPCC_FLAGS", "").split()
 PER_FILE = {
     "assembly.hip": ["-ffp-contract=off"],
+    # k_bt2_apply's diamond loop is 80 fully unrolled steps per half-diamond (every register index must be a constant):
+    # above LLVM's default budget for `#pragma unroll`, below which the accumulators would live in scratch memory
+    "twostage.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
 }
 
 

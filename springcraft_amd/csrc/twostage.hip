@@ -18,6 +18,7 @@
 // Role in the reference: part of np.linalg.eigh (LAPACK dsyevd) at nma.py:61; LAPACK itself uses the one-stage dsytrd.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "eigh_internal.h"
@@ -1000,8 +1001,8 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
 // Diagnostic build (-DBT2_STAMPS): per wave, the shader cycles between eight points of the diamond loop are summed and left
 // in g_bt2_stamps (read with sc_dbg_bt2_stamps, tools/bt2_stamps.py); no stamp executes in the normal build.
 #ifdef BT2_STAMPS
-__device__ unsigned long long g_bt2_stamps[64 * 8 * 9];
-#define BT2_STAMP_DECL unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
+__device__ unsigned long long g_bt2_stamps[64 * 8 * 17];
+#define BT2_STAMP_DECL unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
 #define BT2_STAMP(i)                                                              \
   {                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                            \
@@ -1009,18 +1010,31 @@ __device__ unsigned long long g_bt2_stamps[64 * 8 * 9];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
     if ((i) != 0 || st_n != 0) st_sum[i] += t_ - st_prev;                         \
     st_prev = t_;                                                                 \
-    if ((i) == 7) ++st_n;                                                         \
+    if ((i) == 15) ++st_n;                                                        \
     __builtin_amdgcn_sched_barrier(0);                                            \
   }
 #define BT2_STAMP_WRITE                                                           \
   if (blockIdx.x < 64 && lane == 0) {                                             \
-    for (int i = 0; i < 8; ++i) g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 9 + i] = st_sum[i]; \
-    g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 9 + 8] = st_n;                      \
+    for (int i = 0; i < 16; ++i) g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 17 + i] = st_sum[i]; \
+    g_bt2_stamps[(blockIdx.x * 8 + (w & 7)) * 17 + 16] = st_n;                    \
   }
 #else
 #define BT2_STAMP_DECL
 #define BT2_STAMP(i)
 #define BT2_STAMP_WRITE
+#endif
+// Diagnostic build (-DBT2_TRACE): s_memtime in front of every MFMA of ONE diamond (workgroup 0, sweep group
+// ngroups / 2, fourth chase position), every wave: g_bt2_trace[wave][half][step] (sc_dbg_bt2_trace, tools/bt2_trace.py).
+#ifdef BT2_TRACE
+__device__ unsigned long long g_bt2_trace[8 * 2 * 81];
+#define BT2_TRACE_POINT(H, f)                                                                       \
+  if (trace_on) {                                                                                   \
+    unsigned long long t_;                                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+    if (lane == 0) g_bt2_trace[((w & 7) * 2 + (H)) * 81 + (f)] = t_;                                \
+  }
+#else
+#define BT2_TRACE_POINT(H, f)
 #endif
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kMini = 16;                          // sweeps per compact-WY block
@@ -1132,7 +1146,9 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restrict__ sb_all, SbLayout SL,
                                                           const int* __restrict__ dia_off, double* __restrict__ z_all,
                                                           long long stride_z, int ncols, int batch, int xcd_map) {
-  constexpr int dbg = BT2_DBG;   // ablation builds only (tools/ablate_bt2.sh): 1 no fragment DMA, 2 no Z traffic, 4 no MFMAs
+  // ablation builds only (tools/ablate_bt2.sh; results are wrong by construction): 1 no fragment DMA, 2 no Z traffic,
+  // 4 one MFMA in ten, 8 no workgroup barriers in the diamond loop, 16 no fragment reads from LDS
+  constexpr int dbg = BT2_DBG;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // ring of 3 half-diamond buffers | transposition tiles
   const int n = SL.n;
   constexpr int kCols = 16 * NW;
@@ -1147,11 +1163,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     mat = blockIdx.y;
     chunk = blockIdx.x;
   }
-  const double* sb = sb_all + (size_t)mat * SL.slab;
+  // (workgroup-uniform, and told so: the fragment addresses below are then scalar arithmetic)
+  const unsigned long long sb_bits = (unsigned long long)(size_t)(sb_all + (size_t)mat * SL.slab);
+  const double* sb = (const double*)(size_t)(
+      ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb_bits >> 32)) << 32) |
+      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb_bits));
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int col = chunk * kCols + 16 * w + fr;          // this lane's column in the accumulator layout
-  const double col_mask = col < ncols ? 1.0 : 0.0;
+  const bool col_ok = col < ncols;
 
   // ---- Z <-> accumulator tiles.  In the accumulator layout a lane owns (row 4 r + fk, column fr): a global access in
   // that shape is 16 columns x 32 bytes per instruction, which the memory path serves at ~3 TB/s (measured: the Z
@@ -1187,7 +1207,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * r + fk + shift;
-      t[r] = stg[fr * 18 + (i < 16 ? i : 15)] * (row0 + 4 * r + fk < n ? col_mask : 0.0);
+      // (a select, not a multiplication by a 0 / 1 mask: f64 VALU work queues behind the MFMAs in flight)
+      const double x = stg[fr * 18 + (i < 16 ? i : 15)];
+      t[r] = (col_ok && row0 + 4 * r + fk < n) ? x : 0.0;
     }
     asm volatile("" ::: "memory");
   };
@@ -1221,6 +1243,41 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     tile_to_rows(t, v);
     store_rows(v, row0);
   };
+  // the same in pieces of a few instructions (one piece per MFMA in the diamond loop): one column half per piece, the
+  // tile that sticks out of the matrix handled by lane predicates instead of a second code path
+  auto store_half = [&](zptr zc, bool col_in, const d2u& v, int row0) {
+    if (col_in) {
+      if (row0 + gr + 1 < n) *(z2ptr)(zc + row0) = v;
+      else if (row0 + gr < n) zc[row0] = v[0];
+    }
+  };
+  auto store_rows_a = [&](const Raw& v, int row0) { store_half(za, col_a < ncols, v.a, row0); };
+  auto store_rows_b = [&](const Raw& v, int row0) { store_half(zb, col_b < ncols, v.b, row0); };
+  // scatter_tile in two pieces: raw tile -> transposition tile -> four values per lane (scatter_in); masks and the move
+  // into the accumulator layout a few MFMAs later, when the LDS reads have come back (scatter_out)
+  auto scatter_in = [&](const Raw& raw, double (&tmp)[4], int row0) {
+    *(d2u*)(stg + gc * 18 + gr) = raw.a;
+    *(d2u*)(stg + (gc + 8) * 18 + gr) = raw.b;
+    asm volatile("" ::: "memory");
+    const int shift = row0 < n - 16 ? 0 : row0 - (n - 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + fk + shift;
+      tmp[r] = stg[fr * 18 + (i < 16 ? i : 15)];
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto scatter_out = [&](d4& t, const double (&tmp)[4], int row0) {
+    double x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x[r] = (col_ok && row0 + 4 * r + fk < n) ? tmp[r] : 0.0;
+      // (pinned here: the values are only used by the next diamond, and the compiler would otherwise sink the selects
+      // to the end of this one, where nothing overlaps them)
+      asm volatile("" : "+v"(x[r]));
+    }
+    t = d4{x[0], x[1], x[2], x[3]};
+  };
   // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a half-diamond; the waves share the instructions.
   // Issued from inline asm: hipcc then keeps no scoreboard entry for them (with the builtin it guards later LDS reads
   // and register reuse with vmcnt(0), i.e. waits for the DMA it has just issued); their completion is counted by hand:
@@ -1228,16 +1285,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   const unsigned lds_base = (unsigned)(size_t)(lvoid)lds;
   constexpr int kDmaInstr = kHalfDoubles * 8 / 1024;          // 40 per half
   constexpr int kDmaPer = (kDmaInstr + NW - 1) / NW;          // per wave: 5 (8 waves) or 10 (4 waves)
-  // this wave's j-th instruction of the half at `src` into ring slot `slot`
+  // this wave's j-th instruction of the half at `src` into ring slot `slot`.  Address = scalar base (uniform: the half's
+  // address + 1024 q) + one 32-bit lane offset, so that no per-instruction vector address stays live across the loop
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned voff = (unsigned)lane * 16u;
   auto dma_one = [&](const double* src, int slot, int j) {
-    const int q = w + NW * j;
+    const int q = wu + NW * j;
     if (q < kDmaInstr) {
       unsigned keep;
-      const char* gq = (const char*)src + lane * 16 + q * 1024;
+      const unsigned long long ga = (unsigned long long)(size_t)src + (unsigned long long)q * 1024ull;
+      // (the builtin returns int: widen through unsigned, or a low half with bit 31 set would smear into the high half)
+      const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
+      const unsigned ga_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
+      const unsigned long long sbase = ((unsigned long long)ga_hi << 32) | (unsigned long long)ga_lo;
       const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * kHalfDoubles) * 8u + (unsigned)q * 1024u);
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
-                   : "v"(gq), "s"(lq)
+                   : "v"(voff), "s"(sbase), "s"(lq)
                    : "memory");
     }
   };
@@ -1248,13 +1312,135 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     asm volatile("" ::: "memory");
   };
 
-  d4 zt[8];
-  // the 64 rows finished at the last slide: stored one diamond later, behind the MFMAs of the next diamond's first half
-  d4 zfin[4];
+  // Window registers: three arrays of four tiles (64 rows each).  The window of diamond k is arrays ph | ph + 1 (mod 3),
+  // ph = k mod 3; the third array first holds the 64 rows finished at the last slide (stored behind the MFMAs of this
+  // diamond's first half) and is then refilled with the 64 rows that enter the window at the next slide (scattered in
+  // behind the MFMAs of the second half): sliding is a renaming, no register moves and nothing left outside the shadow
+  // of the MFMA runs.  The diamond body is instantiated once per phase so that every tile index is a constant.
+  d4 zz[12];
   int fin_row = 0;
   bool have_fin = false;
   BT2_STAMP_DECL
+  int S_cur = 0;
+  auto diamond = [&](auto PH, const double* fgrp, int k, int nh, bool more, int& slot, int win) {
+    constexpr int ph = decltype(PH)::value;
+#ifdef BT2_TRACE
+    const bool trace_on = blockIdx.x == 0 && S_cur == SL.ngroups / 2 && k == 3;
+#endif
+#define ZT(rt) zz[4 * ((ph + (rt) / 4) % 3) + (rt) % 4]
+    Raw zn[2], fin_rows;
+#pragma unroll
+    for (int H = 0; H < 2; ++H) {
+      const int q = 2 * k + H;                               // half index inside the group
+      const double* ldsH = lds + slot * kHalfDoubles + lane;
+      const int slot_pre = slot == 0 ? 2 : slot - 1;         // ring slot of half q + 2 (= the one half q - 1 has left)
+      // (past the end of the group the last half is fetched again, into a slot nobody reads: no branch in the loop)
+      const double* src_pre = fgrp + (size_t)(q + 2 < nh ? q + 2 : nh - 1) * kHalfDoubles;
+      BT2_STAMP(7 * H)
+      if (!(dbg & 8)) barrier();   // half q complete in LDS (every wave waited for its own part); half q - 1 finished
+      BT2_STAMP(7 * H + 1)
+      // ---- 80 MFMAs: minis st = 3 - 2 H and 2 - 2 H, everything else in their shadow: the DMA of half q + 2; in the
+      // first half the store of the rows finished at the last slide (through the transposition tile, then to memory);
+      // the loads of the 64 rows that enter the window at the slide and their way through the transposition tile into
+      // the spare array (issued and consumed in EVERY iteration - after the last diamond of a group they are not needed,
+      // the clamped addresses are still valid: hipcc's wait-count bookkeeping is not path sensitive, and loads that
+      // are only issued / consumed under `more` stay "maybe pending" around the loop, which costs a vmcnt(0) wherever
+      // their registers are reused).
+      // One MFMA at a time: what else the half has to do is cut into pieces of a few instructions each, and at most one
+      // piece sits in front of every MFMA, so that it issues while the previous MFMA occupies the matrix pipe (64
+      // cycles).  (Measured with the in-kernel stamps: with the same work bunched between groups of 4 or 8 MFMAs a wave
+      // spends as long issuing its ~600 other instructions per half as the pipe needs for its 80 MFMAs, and the second
+      // wave of the SIMD cannot fill the holes because it runs the same pattern.)
+      d4 wa = d4{0, 0, 0, 0};
+      constexpr int kAhead = 8;                               // fragments in flight between LDS and the MFMA that uses them
+      double fq[kAhead];
+      double sc[4];                                           // a new tile between the transposition tile and its select
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) fq[j] = ldsH[j * 64];
+#pragma unroll
+      for (int f = 0; f < ((dbg & 4) ? 8 : kHalfFrags); ++f) {
+        // ---- this step's piece
+        if (f < kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f);
+        if (!(dbg & 2)) {
+          if (H == 0) {
+            // rows entering at the slide, tiles 0 and 1: requested right after the half's DMA instructions (the compiler
+            // does not see those: its vmcnt for the first use of a row then covers them, being older, and nothing younger)
+            if (f == kDmaPer + 1) load_raw(zn[0], win + 128);
+            if (f == kDmaPer + 3) load_raw(zn[1], win + 128 + 16);
+            // rows finished at the last slide: tile i through the transposition tile at step 14 + 14 i, column halves a / b
+            // stored at steps 20 + 14 i and 22 + 14 i (the last store is 14 MFMAs before the vmcnt(0) of the half)
+            if (have_fin) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (f == 14 + 14 * i) tile_to_rows(ZT(8 + i), fin_rows);
+                if (f == 20 + 14 * i) store_rows_a(fin_rows, fin_row + 16 * i);
+                if (f == 22 + 14 * i) store_rows_b(fin_rows, fin_row + 16 * i);
+              }
+            }
+          } else {
+            // new rows: tiles 0, 1 (requested in the first half) go through the transposition tile at steps 8 / 16 and
+            // into the spare array six steps later; tiles 2, 3 are requested at steps 24 / 26, scattered at 60 / 68
+            if (f == 8) scatter_in(zn[0], sc, win + 128);
+            if (f == 14) scatter_out(ZT(8), sc, win + 128);
+            if (f == 16) scatter_in(zn[1], sc, win + 128 + 16);
+            if (f == 22) scatter_out(ZT(9), sc, win + 128 + 16);
+            if (f == 24) load_raw(zn[0], win + 128 + 32);
+            if (f == 26) load_raw(zn[1], win + 128 + 48);
+            if (f == 60) scatter_in(zn[0], sc, win + 128 + 32);
+            if (f == 66) scatter_out(ZT(10), sc, win + 128 + 32);
+            if (f == 68) scatter_in(zn[1], sc, win + 128 + 48);
+            if (f == 74) scatter_out(ZT(11), sc, win + 128 + 48);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef BT2_STAMPS
+        if (f == 16 || f == 32 || f == 48 || f == 64) BT2_STAMP(7 * H + 1 + f / 16)
+#endif
+        BT2_TRACE_POINT(H, f)
+        // ---- the MFMA
+        {
+          const int st = 3 - 2 * H - f / kMiniFrags, p = f % kMiniFrags;
+          const double a = fq[f % kAhead];
+          if (p < 20) {            // W += V^T Z: one accumulator (a dependent chain of this MFMA issues at the full
+            const int rt = st + p / 4, r = p % 4;   // rate of one per 64 cycles: tools/probe_mini_chain.hip)
+            if (p == 0) wa = d4{0, 0, 0, 0};
+            wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ZT(rt)[r], wa, 0, 0, 0);
+          } else {                 // Z -= (V T) W: the five row tiles take turns
+            const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
+            ZT(rt) = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], ZT(rt), 0, 0, 0);
+          }
+        }
+        // ---- the fragments kAhead steps ahead take the registers the last two MFMAs have read (two per LDS instruction)
+        if ((f & 1) && f + kAhead - 1 < kHalfFrags && !(dbg & 16)) {
+          fq[(f - 1) % kAhead] = ldsH[(f + kAhead - 1) * 64];
+          if (f + kAhead < kHalfFrags) fq[f % kAhead] = ldsH[(f + kAhead) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      BT2_TRACE_POINT(H, 80)
+      BT2_STAMP(7 * H + 6)
+      wait_vm0();                  // this wave's part of half q + 1 (issued one half ago) and of half q + 2, the stores
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    // ---- slide by 64 rows = the next phase.  After the last diamond of a group the whole window goes back to memory.
+    BT2_STAMP(14)
+    if (more) {
+      fin_row = win;
+      have_fin = true;
+    } else {
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) store_tile(ZT(t), win + 16 * t);
+      }
+      have_fin = false;
+    }
+    BT2_STAMP(15)
+    // nothing of this diamond may sink into the next one: behind its LDS-DMA issue the compiler would wait vmcnt(0) for it
+    __builtin_amdgcn_sched_barrier(0);
+#undef ZT
+  };
   for (int S = SL.ngroups - 1; S >= 0; --S) {
+    S_cur = S;
     const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
     const int nh = 2 * nk;                                    // halves of this group, streamed back to back
     int win = S * kG + 1;
@@ -1264,7 +1450,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) load_raw(raw[rt], win + 16 * rt);
 #pragma unroll
-      for (int rt = 0; rt < 8; ++rt) scatter_tile(zt[rt], raw[rt], win + 16 * rt);
+      for (int rt = 0; rt < 8; ++rt) scatter_tile(zz[rt], raw[rt], win + 16 * rt);
     }
     barrier();                       // every wave has left the previous group: the whole ring is free
     if (!(dbg & 1)) {
@@ -1274,100 +1460,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     wait_vm0();
     __builtin_amdgcn_sched_barrier(0);
     int slot = 0;                    // ring slot of the half about to run
-    for (int k = 0; k < nk; ++k) {
+    int ph = 0;
+    for (int k = 0; k < nk; ++k, win += 64) {
       const bool more = k + 1 < nk;
-      Raw zn[4], fin_rows;
-#pragma unroll
-      for (int H = 0; H < 2; ++H) {
-        const int q = 2 * k + H;                               // half index inside the group
-        const double* ldsH = lds + slot * kHalfDoubles + lane;
-        const int slot_pre = slot == 0 ? 2 : slot - 1;         // ring slot of half q + 2 (= the one half q - 1 has left)
-        const double* src_pre = fgrp + (size_t)(q + 2) * kHalfDoubles;
-        const bool pre = q + 2 < nh;
-        BT2_STAMP(H == 0 ? 0 : 3)
-        barrier();                   // half q complete in LDS (every wave waited for its own part); half q - 1 finished
-        BT2_STAMP(H == 0 ? 1 : 4)
-        // ---- 80 MFMAs: minis st = 3 - 2 H and 2 - 2 H.  Fragments in groups of 8: the next group is read from LDS while
-        // the MFMAs of the current one issue.  Everything else is issued in the shadow of these MFMA runs, a little per
-        // group: the DMA of half q + 2, in the first half the store of the rows finished at the last slide (LDS
-        // transposition one group, the global store the next), in the second half the loads of the 64 rows that enter
-        // the window at the slide (raw values, scattered and masked at the slide; issued and consumed in EVERY
-        // iteration - after the last diamond of a group they are not needed, the clamped addresses are still valid:
-        // hipcc's wait-count bookkeeping is not path sensitive, and loads that are only issued / consumed under `more`
-        // stay "maybe pending" around the loop, which costs a vmcnt(0) wherever their registers are reused).
-        d4 wa = d4{0, 0, 0, 0}, wb = d4{0, 0, 0, 0}, ww = d4{0, 0, 0, 0};
-        double fa[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fa[0][j] = ldsH[j * 64];
-#pragma unroll
-        for (int g = 0; g < ((dbg & 4) ? 1 : kHalfFrags / 8); ++g) {
-          if (g + 1 < kHalfFrags / 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fa[(g + 1) & 1][j] = ldsH[((g + 1) * 8 + j) * 64];
-          }
-          if (g < 5 && pre && !(dbg & 1)) {
-#pragma unroll
-            for (int j = g * ((kDmaPer + 4) / 5); j < (g + 1) * ((kDmaPer + 4) / 5) && j < kDmaPer; ++j)
-              dma_one(src_pre, slot_pre, j);
-          }
-          if (H == 0 && g >= 1 && g <= 5 && have_fin && !(dbg & 2)) {
-            if (g >= 2) store_rows(fin_rows, fin_row + 16 * (g - 2));
-            if (g <= 4) tile_to_rows(zfin[g - 1], fin_rows);
-          }
-          if (H == 1 && g < 2 && !(dbg & 2)) {
-            load_raw(zn[2 * g], win + 128 + 32 * g);
-            load_raw(zn[2 * g + 1], win + 128 + 32 * g + 16);
-          }
-          __builtin_amdgcn_sched_barrier(0);   // keep the reads of group g + 1 in front of the MFMAs of group g
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int f = 8 * g + j;
-            const int st = 3 - 2 * H - f / kMiniFrags, p = f % kMiniFrags;
-            const double a = fa[g & 1][j];
-            if (p < 20) {            // W += V^T Z: two accumulators take turns
-              const int rt = st + p / 4, r = p % 4;
-              if (p == 0) wa = d4{0, 0, 0, 0};
-              if (p == 1) wb = d4{0, 0, 0, 0};
-              if (p & 1) wb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zt[rt][r], wb, 0, 0, 0);
-              else wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zt[rt][r], wa, 0, 0, 0);
-            } else {                 // Z -= (V T) W: the five row tiles take turns
-              if (p == 20) ww = wa + wb;
-              const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
-              zt[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ww[r], zt[rt], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        BT2_STAMP(H == 0 ? 2 : 5)
-        wait_vm0();                  // this wave's part of half q + 1 (issued one half ago) and of half q + 2, the stores
-        slot = slot == 2 ? 0 : slot + 1;
-      }
-      // ---- slide by 64 rows: the finished rows move to zfin, the window shifts, the new rows are scattered in (the
-      // shift is done after the last diamond of a group as well: its result is not used, but the new rows' loads must
-      // have their first use on every path, see above)
-      BT2_STAMP(6)
-      if (more) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) zfin[t] = zt[t];
-        fin_row = win;
-        have_fin = true;
-      } else {
-        if (!(dbg & 2)) {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) store_tile(zt[t], win + 16 * t);
-        }
-        have_fin = false;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        zt[t] = zt[t + 4];
-        scatter_tile(zt[t + 4], zn[t], win + 128 + 16 * t);
-      }
-      win += 64;
-      BT2_STAMP(7)
-      // nothing of the slide (the scatter of the new rows is the first use of their loads) may sink into the next
-      // diamond: behind its LDS-DMA issue the compiler would wait vmcnt(0) for it
-      __builtin_amdgcn_sched_barrier(0);
+      if (ph == 0) diamond(std::integral_constant<int, 0>{}, fgrp, k, nh, more, slot, win);
+      else if (ph == 1) diamond(std::integral_constant<int, 1>{}, fgrp, k, nh, more, slot, win);
+      else diamond(std::integral_constant<int, 2>{}, fgrp, k, nh, more, slot, win);
+      ph = ph == 2 ? 0 : ph + 1;
     }
   }
   BT2_STAMP_WRITE
@@ -1799,10 +1898,20 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
 
 int sb_band_width() { return kB; }
 
+// ---- diagnostic build only (-DBT2_TRACE): time stamps in front of every MFMA of one diamond, [wave][half][81]
+extern "C" int sc_dbg_bt2_trace(unsigned long long* out) {
+#ifdef BT2_TRACE
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_trace), sizeof(unsigned long long) * 8 * 2 * 81) == hipSuccess ? 0 : 5;
+#else
+  (void)out;
+  return 1;
+#endif
+}
+
 // ---- diagnostic build only: per-wave segment sums of k_bt2_apply (first 64 workgroups x 8 waves x (8 sums + count))
 extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
 #ifdef BT2_STAMPS
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_stamps), sizeof(unsigned long long) * 64 * 8 * 9) == hipSuccess ? 0 : 5;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_stamps), sizeof(unsigned long long) * 64 * 8 * 17) == hipSuccess ? 0 : 5;
 #else
   (void)out;
   return 1;

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Ablation of k_bt2_apply on the GPU box: rebuild twostage.hip with BT2_DBG = 1 (no fragment DMA), 4 (one MFMA group per
-# product only), 5 (both) and time the bench step; results are wrong by construction.  (2 = no Z traffic lets the
-# compiler delete the products as dead code: not meaningful.)
+# Ablation of k_bt2_apply on the GPU box: rebuild twostage.hip with BT2_DBG = 1 (no fragment DMA), 4 (one MFMA in ten),
+# 8 (no workgroup barriers), 16 (no fragment reads from LDS) or sums of these and time the bench step; results are wrong
+# by construction.  (2 = no Z traffic lets the compiler delete the products as dead code: not meaningful.)
 set -u
 cd ${GRAFT_REPO_ROOT:-.}
 for d in ${1:-0 1 4 5}; do

@@ -20,15 +20,21 @@ coord = torch.from_numpy(np.stack([np.random.RandomState(s).rand(N, 3) * box for
 solver = DeviceBatchSolver(N, B, sc.HinsenForceField())
 solver.solve(coord)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * (64 * 8 * 9))()
+buf = (C.c_ulonglong * (64 * 8 * 17))()
 rc = _hip.lib().sc_dbg_bt2_stamps(buf)
-a = np.array(buf, dtype=np.float64).reshape(64, 8, 9)
-print("rc", rc, "diamonds per wave", a[0, 0, 8])
-names = ["slide end -> barrier 0 arrive (loop top)", "barrier 0 wait", "half 0: minis 3, 2 (+ DMA issue, deferred stores)",
-         "vmcnt wait after half 0", "barrier 1 wait", "half 1: minis 1, 0 (+ DMA issue, row loads)",
-         "vmcnt wait after half 1", "slide (shift, scatter)"]
-per = a[:, :, :8] / np.maximum(a[:, :, 8:9], 1)
+a = np.array(buf, dtype=np.float64).reshape(64, 8, 17)
+print("rc", rc, "diamonds per wave", a[0, 0, 16])
+names = []
+for h in range(2):
+    names += [f"half {h}: arrive at its barrier (since the last stamp)", f"half {h}: barrier wait", f"half {h}: MFMA steps  0 .. 15",
+              f"half {h}: MFMA steps 16 .. 31", f"half {h}: MFMA steps 32 .. 47", f"half {h}: MFMA steps 48 .. 63",
+              f"half {h}: MFMA steps 64 .. 79"]
+names += ["vmcnt wait after half 1", "slide"]
+per = a[:, :, :16] / np.maximum(a[:, :, 16:17], 1)
 tot = per.sum(-1).mean()
 for i, nm in enumerate(names):
-    print(f"{nm:40s} mean {per[:, :, i].mean():9.0f} cyc  min {per[:, :, i].min():9.0f}  max {per[:, :, i].max():9.0f}  {100 * per[:, :, i].mean() / tot:5.1f} %")
-print(f"{'per diamond':40s} mean {tot:9.0f} cyc")
+    print(f"{nm:52s} mean {per[:, :, i].mean():8.0f} cyc  min {per[:, :, i].min():8.0f}  max {per[:, :, i].max():8.0f}  {100 * per[:, :, i].mean() / tot:5.1f} %")
+print(f"{'per diamond':52s} mean {tot:8.0f} cyc")
+print("per wave of workgroup 0 (rows = waves, columns = the sixteen segments):")
+for wv in range(8):
+    print("  wave", wv, " ".join(f"{per[0, wv, i]:6.0f}" for i in range(16)), f"  sum {per[0, wv].sum():7.0f}")

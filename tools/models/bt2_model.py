@@ -116,10 +116,10 @@ def apply_kernel(frags, Zwin):
     for f, (kind, st, rt, r) in enumerate(steps()):
         if kind == "p1":
             if f % 40 == 0:
-                w = np.zeros((2, 4, 64))            # two accumulators take turns, summed before product 2
-            w[f & 1] = mfma(frags[f], zt[rt, r], w[f & 1])
+                w = np.zeros((4, 64))               # one accumulator per mini (a dependent chain issues at full rate)
+            w = mfma(frags[f], zt[rt, r], w)
         else:
-            zt[rt] = mfma(frags[f], (w[0] + w[1])[r], zt[rt])
+            zt[rt] = mfma(frags[f], w[r], zt[rt])
     out = np.zeros_like(Zwin)
     for rt in range(8):
         for r in range(4):
