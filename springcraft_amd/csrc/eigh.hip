@@ -88,7 +88,7 @@ Plan make_plan(const sc_ctx* ctx, int n, int batch, bool vectors) {
   P.n_syr2k = npanels * batch;
   P.two = two_stage_for(ctx, n, batch);
   if (P.two) {
-    P.off_sb = take(sb_slab_doubles(n, vectors ? n : 0, &P.SL) * 8 * batch);
+    P.off_sb = take(sb_slab_doubles(n, batch, &P.SL) * 8 * batch);
     P.off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
     P.n_syr2k = std::max(P.n_syr2k, sb_desc_count(n, batch));
   }
@@ -311,7 +311,7 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
   int n_bt = 0;
   int n_tri_desc = npanels * batch;
   if (two) {
-    off_sb = take(sb_slab_doubles(n, d_v ? m : 0, &SL) * 8 * batch);
+    off_sb = take(sb_slab_doubles(n, batch, &SL) * 8 * batch);
     off_dia = take(sizeof(int) * ((size_t)n / 64 + 8));
     n_tri_desc = std::max(n_tri_desc, sb_desc_count(n, batch));
   }

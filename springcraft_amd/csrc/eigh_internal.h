@@ -110,6 +110,8 @@ struct SbLayout {
   long long xv;       // [X1|X2|V], n x 192
   long long qrpart, qrpiv;   // panel-QR partial Gram rows / pivot row (two copies each)
   long long qrpart8;         // blocked panel QR: per-chunk partial products of an inner block, nchunk x 8 x 64
+  long long xsplit;   // K slices of X1 and X2 when the SYMM runs split-K: 2 x symm_split x (n x 64)
+  int symm_split;     // 1: no split
   long long small;    // split-K slices of V^T [X1|X2|V]
   long long cmat;     // [T; T; -S/2], 192 x 64
   long long ab;       // band storage 128 x n
@@ -119,8 +121,8 @@ struct SbLayout {
   long long frag;     // diamonds: MFMA fragments of V^T and -(V T), 160 x 64 doubles each (k_dia_tfactor2 -> k_bt2_apply)
   long long tau2;     // ndia x 64
 };
-// ncols: columns of Z the back-transformation will be applied to (0: eigenvalues only)
-size_t sb_slab_doubles(int n, int ncols, SbLayout* out);
+// batch: matrices of the solve (few matrices: the SYMM of the band reduction is cut into K slices, which need room)
+size_t sb_slab_doubles(int n, int batch, SbLayout* out);
 int sb_desc_count(int n, int batch);
 int sb_band_width();
 // d_a: column-major lower triangle valid.  On exit d, e (and the stage-1 tau) are in the tri slab, the stage-1

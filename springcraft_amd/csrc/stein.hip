@@ -20,44 +20,89 @@ namespace {
 
 constexpr double kEpsS = 2.220446049250313e-16;
 
+// One WAVE per requested eigenvalue: multisection.  Every round the 64 lanes count the eigenvalues below 64 equally
+// spaced shifts inside the current bracket (the Sturm recurrence is sequential in n but independent between shifts, so
+// a round costs what one bisection step costs) and the bracket shrinks 65-fold: ~9 rounds instead of ~53 bisection
+// steps; a few plain bisection steps then close the bracket to neighbouring floating-point numbers as before.
 __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ tri_all, TriLayout TL, int il,
                                                     int m, double* __restrict__ w_all, long long stride_w) {
   const double* tri = tri_all + (size_t)blockIdx.y * TL.slab;
   const double* d = tri + TL.d;
   const double* e = tri + TL.e;
   const int n = TL.n;
-  // Gershgorin bounds (every thread redundantly; n is at most a few 10^4 and this runs once)
+  const int lane = threadIdx.x;
+  // Gershgorin bounds, lanes strided over the rows
   double lo = 1e300, hi = -1e300, emax = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = lane; i < n; i += 64) {
     const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i < n - 1 ? fabs(e[i]) : 0.0;
     lo = fmin(lo, d[i] - el - er);
     hi = fmax(hi, d[i] + el + er);
     emax = fmax(emax, er);
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, off));
+    hi = fmax(hi, __shfl_xor(hi, off));
+    emax = fmax(emax, __shfl_xor(emax, off));
+  }
   const double span = fmax(fabs(lo), fabs(hi));
   const double pivmin = fmax(2.2250738585072014e-308 * fmax(1.0, emax * emax), 1e-290);
   lo -= 2.0 * kEpsS * span * n + 2.0 * pivmin;
   hi += 2.0 * kEpsS * span * n + 2.0 * pivmin;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.x;
   if (j >= m) return;
   const int k = il + j;
-  double a = lo, b = hi;
+  // (the recurrence is a chain of divisions; d and e come in chunks of 16 requested together, so that the chain waits
+  // for memory once per chunk instead of once per row)
+  auto count_below = [&](double x) {
+    int cnt = 0;
+    double q = d[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.0;
+    for (int i0 = 1; i0 < n; i0 += 16) {
+      double dd[16], ee[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = min(i0 + u, n - 1);
+        dd[u] = d[i];
+        ee[u] = e[i - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (i0 + u < n) {
+          q = dd[u] - x - ee[u] * ee[u] / q;
+          if (fabs(q) < pivmin) q = -pivmin;
+          cnt += q < 0.0;
+        }
+      }
+    }
+    return cnt;
+  };
+  double a = lo, b = hi;   // invariant: count_below(a) <= k < count_below(b)
+  for (int round = 0; round < 16; ++round) {
+    const double width = b - a;
+    const double x = a + width * ((double)(lane + 1) / 65.0);
+    if (__any(!(x > a && x < b))) break;      // the bracket is down to a few numbers (decided for the whole wave)
+    const int cnt = count_below(x);
+    const unsigned long long above = __ballot(cnt > k);
+    double nb = b, na = a;
+    if (above != 0ull) {
+      const int p = __ffsll((long long)above) - 1;   // first shift that has more than k eigenvalues below it
+      nb = __shfl(x, p);
+      if (p > 0) na = __shfl(x, p - 1);
+    } else {
+      na = __shfl(x, 63);
+    }
+    a = na;
+    b = nb;
+    if (!(b - a < width)) break;
+  }
   for (int it = 0; it < 120; ++it) {
     const double mid = 0.5 * (a + b);
     if (mid <= a || mid >= b) break;
-    int cnt = 0;
-    double q = d[0] - mid;
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < 0.0;
-    for (int i = 1; i < n; ++i) {
-      const double ee = e[i - 1];
-      q = d[i] - mid - ee * ee / q;
-      if (fabs(q) < pivmin) q = -pivmin;
-      cnt += q < 0.0;
-    }
-    if (cnt > k) b = mid; else a = mid;
+    if (count_below(mid) > k) b = mid; else a = mid;
   }
-  w_all[(size_t)blockIdx.y * stride_w + j] = 0.5 * (a + b);
+  if (lane == 0) w_all[(size_t)blockIdx.y * stride_w + j] = 0.5 * (a + b);
 }
 
 __device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {
@@ -101,23 +146,34 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
 #define AT(arr, k) arr[(size_t)(k) * m + j]
   // LU factorisation of T - lam I with partial pivoting (row k against row k+1)
   double p = d[0] - lam, q = n > 1 ? e[0] : 0.0, r = 0.0;
-  for (int k = 0; k < n - 1; ++k) {
-    const double sub = e[k];
-    const double dn = d[k + 1] - lam;
-    const double en = (k + 2 < n) ? e[k + 1] : 0.0;
-    if (fabs(sub) > fabs(p)) {          // swap: pivot row is (sub, dn, en)
-      const double mult = p / sub;
-      AT(u0, k) = sub; AT(u1, k) = dn; AT(u2, k) = en; AT(lm, k) = mult; AT(pv, k) = 1.0;
-      p = q - mult * dn;
-      q = r - mult * en;
-      r = 0.0;
-    } else {
-      if (fabs(p) < tiny) p = copysign(tiny, p == 0.0 ? 1.0 : p);
-      const double mult = sub / p;
-      AT(u0, k) = p; AT(u1, k) = q; AT(u2, k) = r; AT(lm, k) = mult; AT(pv, k) = 0.0;
-      p = dn - mult * q;
-      q = en - mult * r;
-      r = 0.0;
+  for (int k0 = 0; k0 < n - 1; k0 += 8) {
+    double e8[9], d8[8];   // e[k0 .. k0 + 8], d[k0 + 1 .. k0 + 8], requested together
+#pragma unroll
+    for (int u = 0; u < 9; ++u) e8[u] = e[min(k0 + u, n - 2)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d8[u] = d[min(k0 + 1 + u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < n - 1) {
+        const double sub = e8[u];
+        const double dn = d8[u] - lam;
+        const double en = (k + 2 < n) ? e8[u + 1] : 0.0;
+        if (fabs(sub) > fabs(p)) {          // swap: pivot row is (sub, dn, en)
+          const double mult = p / sub;
+          AT(u0, k) = sub; AT(u1, k) = dn; AT(u2, k) = en; AT(lm, k) = mult; AT(pv, k) = 1.0;
+          p = q - mult * dn;
+          q = r - mult * en;
+          r = 0.0;
+        } else {
+          if (fabs(p) < tiny) p = copysign(tiny, p == 0.0 ? 1.0 : p);
+          const double mult = sub / p;
+          AT(u0, k) = p; AT(u1, k) = q; AT(u2, k) = r; AT(lm, k) = mult; AT(pv, k) = 0.0;
+          p = dn - mult * q;
+          q = en - mult * r;
+          r = 0.0;
+        }
+      }
     }
   }
   if (fabs(p) < tiny) p = copysign(tiny, p == 0.0 ? 1.0 : p);
@@ -125,22 +181,55 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
 
   for (int i = 0; i < n; ++i) X[i] = hash_unit((unsigned)j + 1u, (unsigned)i + 1u);
   for (int iter = 0; iter < 4; ++iter) {
-    // forward: apply the row interchanges and multipliers
-    for (int k = 0; k < n - 1; ++k) {
-      double xk = X[k], xn = X[k + 1];
-      if (AT(pv, k) != 0.0) { const double t = xk; xk = xn; xn = t; }
-      xn -= AT(lm, k) * xk;
-      X[k] = xk;
-      X[k + 1] = xn;
+    // forward: apply the row interchanges and multipliers.  The running entry stays in a register, the factors and
+    // the next entries of x come in chunks of 8 rows requested together (the loop is a dependent chain: without that it
+    // waits for memory in every row)
+    {
+      double xk = X[0];
+      for (int k0 = 0; k0 < n - 1; k0 += 8) {
+        double xn8[8], pv8[8], lm8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u, n - 2);
+          xn8[u] = X[k + 1];
+          pv8[u] = AT(pv, k);
+          lm8[u] = AT(lm, k);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (k0 + u < n - 1) {
+            double xn = xn8[u];
+            if (pv8[u] != 0.0) { const double t = xk; xk = xn; xn = t; }
+            xn -= lm8[u] * xk;
+            X[k0 + u] = xk;
+            xk = xn;
+          }
+        }
+      }
+      X[n - 1] = xk;
     }
-    // back substitution with the three diagonals of U
+    // back substitution with the three diagonals of U, same chunking
     double x1 = 0.0, x2 = 0.0, nrm = 0.0;
-    for (int k = n - 1; k >= 0; --k) {
-      const double xv = (X[k] - AT(u1, k) * x1 - AT(u2, k) * x2) / AT(u0, k);
-      X[k] = xv;
-      x2 = x1;
-      x1 = xv;
-      nrm = fmax(nrm, fabs(xv));
+    for (int k0 = n - 1; k0 >= 0; k0 -= 8) {
+      double xr[8], a0[8], a1[8], a2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = max(k0 - u, 0);
+        xr[u] = X[k];
+        a0[u] = AT(u0, k);
+        a1[u] = AT(u1, k);
+        a2[u] = AT(u2, k);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k0 - u >= 0) {
+          const double xv = (xr[u] - a1[u] * x1 - a2[u] * x2) / a0[u];
+          X[k0 - u] = xv;
+          x2 = x1;
+          x1 = xv;
+          nrm = fmax(nrm, fabs(xv));
+        }
+      }
     }
     // rescale (max-norm) to stay in range; final 2-normalisation is done by the QR step
     const double s = nrm > 0.0 ? 1.0 / nrm : 1.0;
@@ -206,16 +295,22 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                   GemmDesc* d_descs /* 2 * batch */) {
   hipStream_t st = ctx->stream;
   const int m = iu - il + 1;
-  hipLaunchKernelGGL(k_sturm_range, dim3((unsigned)((m + 63) / 64), (unsigned)batch), dim3(64), 0, st, d_tri_ws,
-                     TL, il, m, d_w, stride_w);
+  PhaseTimer t_sturm(ctx, "sturm", st), t_stein(ctx, "stein", st), t_qr(ctx, "cholqr", st);
+  t_sturm.start();
+  hipLaunchKernelGGL(k_sturm_range, dim3((unsigned)m, (unsigned)batch), dim3(64), 0, st, d_tri_ws, TL, il, m, d_w, stride_w);
+  t_sturm.stop();
   if (!d_x) {
+    t_sturm.finish();
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
   }
   const long long stride_ws = (long long)stein_workspace_doubles(n, m);
   double* fac = d_ws;
+  t_stein.start();
   hipLaunchKernelGGL(k_stein, dim3((unsigned)((m + 63) / 64), (unsigned)batch), dim3(64), 0, st, d_tri_ws, TL, m,
                      d_w, stride_w, fac, stride_ws, d_x, stride_x);
+  t_stein.stop();
+  t_qr.start();
   // CholQR2
   const int splits = std::max(1, std::min(32, n / 512));
   std::vector<GemmDesc> h(2 * (size_t)batch);
@@ -252,6 +347,8 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     SC_HIP(ctx, hipStreamSynchronize(st));  // `h` is reused by the next round
     (void)x_cur;
   }
+  t_qr.stop();
+  t_sturm.finish(); t_stein.finish(); t_qr.finish();
   SC_HIP(ctx, hipGetLastError());
   return SC_OK;
 }

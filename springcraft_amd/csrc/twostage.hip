@@ -468,6 +468,19 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
   }
 }
 
+// X1 / X2 = sum of their K slices (split-K SYMM, few matrices): blockIdx.y = column of [X1 | X2], rows r0 .. n - 1
+__global__ __launch_bounds__(256) void k_sum_xslices(double* __restrict__ sb_all, SbLayout SL, int r0) {
+  const int n = SL.n, p = SL.symm_split;
+  double* sb = sb_all + (size_t)blockIdx.z * SL.slab;
+  const int which = blockIdx.y / kB, c = blockIdx.y % kB;
+  const int r = r0 + blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const double* src = sb + SL.xsplit + (size_t)which * p * n * kB + (size_t)c * n + r;
+  double s = 0.0;
+  for (int q = 0; q < p; ++q) s += src[(size_t)q * n * kB];
+  sb[SL.xv + (size_t)(which * kB + c) * n + r] = s;
+}
+
 // One workgroup per matrix: T (larft, forward columnwise) from tau and G = V^T V;  S = T^T (V^T X) T;
 // C = [T; T; -S/2]  (3 kB x kB, column-major), the right-hand factor of  W = [X1 | X2 | V] C.
 __global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri_all, TriLayout TL,
@@ -1472,11 +1485,118 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   BT2_STAMP_WRITE
 }
 
+// ---- few columns (partial spectrum): one launch per WAVEFRONT of diamonds ------------------------------------------
+// k_bt2_apply gives a workgroup 16 NW columns and lets it walk all diamonds in order: with the ~100 columns of a
+// partial-spectrum solve that is two workgroups on the whole chip, each applying ~n^2 / 8192 diamonds one after the other
+// (config C5, n = 24000: 70 000 diamonds, 470 ms).  Diamond (S, k) touches rows 64 S + 1 + 64 k .. + 126 and must follow
+// (S, k - 1) and (S + 1, k .. k + 2): all diamonds with the same t = 3 (Smax - S) + k are independent.  Launch t runs
+// them side by side, one workgroup per (diamond, 64 columns): window from memory, the same 160 MFMAs with the
+// fragments read straight from L2, window back to memory.  n / 64 + 3 n / 64 launches instead of n^2 / 8192 serial steps.
+__global__ __launch_bounds__(256) void k_bt2_wave(const double* __restrict__ sb_all, SbLayout SL,
+                                                  const int* __restrict__ dia_off, double* __restrict__ z_all,
+                                                  long long stride_z, int ncols, int t) {
+  __shared__ double stg_all[4][16 * 18];
+  const int n = SL.n;
+  const int S = SL.ngroups - 1 - (int)blockIdx.x;
+  const int k = t - 3 * (int)blockIdx.x;
+  if (S < 0 || k < 0) return;
+  const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
+  if (k >= nk) return;
+  const double* sb = sb_all + (size_t)blockIdx.z * SL.slab;
+  const double* frag = sb + SL.frag + (size_t)(d0 + k) * kFragDoubles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int col = ((int)blockIdx.y * 4 + w) * 16 + fr;
+  const bool col_ok = col < ncols;
+  const int win = S * kG + 1 + kB * k;
+  double* stg = stg_all[w];
+  const int gc = lane >> 3, gr = (lane & 7) * 2;
+  const int col_a = ((int)blockIdx.y * 4 + w) * 16 + gc, col_b = col_a + 8;
+  double* z_mat = z_all + (size_t)blockIdx.z * stride_z;
+  double* za = z_mat + (size_t)(col_a < ncols ? col_a : ncols - 1) * n + gr;
+  double* zb = z_mat + (size_t)(col_b < ncols ? col_b : ncols - 1) * n + gr;
+  d4 zt[8];
+  // window -> accumulator layout through the wave's transposition tile (same maps as k_bt2_apply)
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt) {
+    const int row0 = win + 16 * rt;
+    const int rs = row0 < n - 16 ? row0 : n - 16;
+    const int shift = row0 < n - 16 ? 0 : row0 - (n - 16);
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (rs >= 0) { a0 = za[rs]; a1 = za[rs + 1]; b0 = zb[rs]; b1 = zb[rs + 1]; }
+    stg[gc * 18 + gr] = a0; stg[gc * 18 + gr + 1] = a1;
+    stg[(gc + 8) * 18 + gr] = b0; stg[(gc + 8) * 18 + gr + 1] = b1;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + fk + shift;
+      const double x = stg[fr * 18 + (i < 16 ? i : 15)];
+      zt[rt][r] = (col_ok && row0 + 4 * r + fk < n) ? x : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // the 160 MFMAs, fragments eight ahead
+  constexpr int kAhead = 8;
+  double fq[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) fq[j] = frag[(size_t)j * 64 + lane];
+  d4 wa = d4{0, 0, 0, 0};
+#pragma unroll
+  for (int f = 0; f < kDiaFrags; ++f) {
+    const int st = 3 - f / kMiniFrags, p = f % kMiniFrags;
+    const double a = fq[f % kAhead];
+    if (p < 20) {
+      const int rt = st + p / 4, r = p % 4;
+      if (p == 0) wa = d4{0, 0, 0, 0};
+      wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zt[rt][r], wa, 0, 0, 0);
+    } else {
+      const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
+      zt[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], zt[rt], 0, 0, 0);
+    }
+    if (f + kAhead < kDiaFrags) fq[f % kAhead] = frag[(size_t)(f + kAhead) * 64 + lane];
+  }
+  // window back to memory
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt) {
+    const int row0 = win + 16 * rt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stg[fr * 18 + 4 * r + fk] = zt[rt][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const double a0 = stg[gc * 18 + gr], a1 = stg[gc * 18 + gr + 1];
+    const double b0 = stg[(gc + 8) * 18 + gr], b1 = stg[(gc + 8) * 18 + gr + 1];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (col_a < ncols) {
+      if (row0 + gr < n) za[row0] = a0;
+      if (row0 + gr + 1 < n) za[row0 + 1] = a1;
+    }
+    if (col_b < ncols) {
+      if (row0 + gr < n) zb[row0] = b0;
+      if (row0 + gr + 1 < n) zb[row0 + 1] = b1;
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================================
 // Layout
-size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
+// K slices of the SYMM X = A22 V: with few matrices its launch has only n / 64 tiles per matrix, each walking a K range of
+// up to n (longest first, but the longest IS the critical path): slices of the K range give the launch 2 - 8 times the
+// workgroups and a fraction of the critical path.  Config C5 (one 24000 x 24000 matrix): 596 -> 307 ms.
+int symm_split_for(int n, int batch) {
+  static const int env = [] { const char* e = getenv("SPRINGCRAFT_SYMM_SPLIT"); return e ? atoi(e) : 0; }();
+  if (env >= 1) return std::min(env, 8);
+  const long long tiles = (long long)batch * ((n + 63) / 64);
+  if (tiles >= 1024 || n < 2048) return 1;
+  // (one 24000 x 24000 matrix: 3 slices 338 ms, 6 slices 307 ms, 8 slices 378 ms of SYMM time)
+  return (int)std::min<long long>(6, (2048 + tiles - 1) / tiles);
+}
+
+size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
   SbLayout L{};
   L.n = n;
   long long off = 0;
@@ -1485,6 +1605,8 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   L.vw = take((long long)n * 2 * kB);
   L.wv = take((long long)n * 2 * kB);
   L.xv = take((long long)n * 3 * kB);
+  L.symm_split = symm_split_for(n, batch);
+  L.xsplit = L.symm_split > 1 ? take((long long)2 * L.symm_split * n * kB) : 0;
   L.qrpart = take((long long)2 * nchunk * kB);
   L.qrpiv = take(2 * (kB + 8));
   L.qrpart8 = take((long long)nchunk * 8 * kB);
@@ -1503,7 +1625,6 @@ size_t sb_slab_doubles(int n, int ncols, SbLayout* out) {
   L.vd = take(ndia * kDiaSize);
   L.frag = take(ndia * kFragDoubles);
   L.tau2 = take(ndia * kG);
-  (void)ncols;
   L.slab = off;
   if (out) *out = L;
   return (size_t)off;
@@ -1555,11 +1676,16 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       X1.b = sb + SL.xv + (size_t)2 * kB * n + r0; X1.sb_k = 1; X1.sb_j = n;
       X1.c = sb + SL.xv + r0; X1.ldc = n;
       X1.m = m; X1.n = kB; X1.k = m; X1.alpha = 1.0; X1.beta = 0.0;
+      if (SL.symm_split > 1) {   // K slices into their own buffers, summed into X1 / X2 by k_sum_xslices
+        X1.c = sb + SL.xsplit + r0;
+        X1.split_stride = (long long)n * kB;
+      }
       g[0] = X1;
       // X2 = strict(L)^T V
       GemmDesc X2 = X1;
       X2.sa_i = n; X2.sa_k = 1; X2.a_tri = 2;
       X2.c = sb + SL.xv + (size_t)kB * n + r0;
+      if (SL.symm_split > 1) X2.c = sb + SL.xsplit + (size_t)SL.symm_split * n * kB + r0;
       g[1] = X2;
       // V^T [X1 | X2 | V], split-K slices
       GemmDesc P{};
@@ -1653,8 +1779,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     if (timed) t_qr.stop();
     const GemmDesc* g = d_descs + (size_t)p * 6 * batch;   // [kind][batch]
     if (timed) t_symm.start();
-    SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, 1, false, true, kGemmAmBk));           // X1 = L V
-    SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, 1, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+    SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAmBk));           // X1 = L V
+    SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+    if (SL.symm_split > 1)
+      hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), 2 * kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
     if (timed) t_symm.stop();
     SC_TRY(launch_gemm_f64(ctx, g + 2 * batch + lo, nb, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
     hipLaunchKernelGGL(k_sb_small, dim3((unsigned)nb), dim3(256), lds_small, ps, tri_h, TL, sb_h, SL, j0);
@@ -1861,7 +1989,23 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     for (auto& e : ev) SC_HIP(ctx, hipEventCreate(&e));
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
-  {
+  // few columns (partial spectrum): one launch per wavefront of independent diamonds, see k_bt2_wave
+  static const int env_wave = [] { const char* e = getenv("SPRINGCRAFT_BT2_WAVE"); return e ? atoi(e) : -1; }();
+  const long long col_wgs = (long long)((ncols + 63) / 64) * batch;
+  const bool wave_path = env_wave >= 0 ? env_wave != 0 : col_wgs <= 16;
+  if (wave_path) {
+    int nk0 = 0;
+    {
+      const std::vector<int> doff = dia_offsets(n);
+      for (size_t S = 0; S + 1 < doff.size(); ++S) nk0 = std::max(nk0, doff[S + 1] - doff[S]);
+    }
+    const int t_last = 3 * (SL.ngroups - 1) + nk0 - 1;
+    for (int t = 0; t <= t_last; ++t) {
+      const int gx = std::min(t / 3, SL.ngroups - 1) + 1;
+      hipLaunchKernelGGL(k_bt2_wave, dim3((unsigned)gx, (unsigned)((ncols + 63) / 64), (unsigned)batch), dim3(256), 0, st,
+                         d_sb_ws, SL, d_dia_off, d_z, stride_z, ncols, t);
+    }
+  } else {
     // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
     // ring of three half-diamond fragment buffers + one 16 x 18 transposition tile per wave
     constexpr size_t lds = sizeof(double) * (3 * kHalfDoubles + 8 * 16 * 18);
@@ -1940,7 +2084,7 @@ extern "C" int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* ban
   TL.n = n; TL.nb = kB;
   TL.d = 0; TL.e = n; TL.tau = 2 * (long long)n; TL.slab = 3 * (long long)n + 64;
   SbLayout SL;
-  const size_t sbd = sb_slab_doubles(n, 0, &SL);
+  const size_t sbd = sb_slab_doubles(n, 1, &SL);
   double *d_a = nullptr, *d_tri = nullptr, *d_sb = nullptr, *d_band = nullptr;
   int* d_off = nullptr;
   GemmDesc* d_desc = nullptr;
