@@ -12,9 +12,14 @@
  *   - plain pointers + sizes only; no C++ / torch types cross this boundary;
  *   - every function returns an int status (SC_OK == 0); no exceptions cross the boundary;
  *     sc_last_error(ctx) returns a human-readable message for the last failure on ctx;
- *   - "host" entry points take host pointers and do their own transfers;
- *     "sc_dev_*" entry points take device pointers valid on the context's device and
- *     enqueue work on the context's stream without synchronising (except where stated);
+ *   - "host" entry points take host pointers and do their own transfers (they synchronise, and
+ *     return the errors of their own call);
+ *     "sc_dev_*" and sc_batch_plan_assemble_f64 take device pointers valid on the context's device
+ *     and only enqueue work on the context's stream: descriptor tables travel through a pinned
+ *     staging arena of the context, and what a solve can only find out on the device (a NaN / Inf
+ *     entry in an input matrix, a failed QL iteration) is reported by the next sc_ctx_synchronize.
+ *     One exception: a two-stage solve of a latency-bound batch (batch * n / 128 <= 1200) waits for
+ *     its persistent bulge chase, whose control block decides whether the chase is complete;
  *   - all matrices are float64; Kirchhoff is (n,n), Hessian (3n,3n), C order, exactly as
  *     numpy returns them in the reference (interaction.py:48,107-109);
  *   - eigenvectors are returned "rows = modes": V[i*n + c] is component c of mode i, the
@@ -113,7 +118,11 @@ int sc_ctx_create(int device, sc_ctx** out);
 int sc_ctx_create_on_stream(int device, void* hip_stream, sc_ctx** out);
 void sc_ctx_destroy(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
-/* Block until everything enqueued on the context's stream has finished. */
+/* Block until everything enqueued on the context's stream has finished.  Returns SC_ERR_NOCONV (LinAlgError in the
+ * Python layer, what np.linalg.eigh raises at nma.py:61) if a device-pointer eigensolve enqueued since the last call
+ * met a matrix with a NaN / Inf entry -- that matrix is solved as the zero matrix and its eigenvalues are returned as
+ * NaN, the other matrices of its batch are unaffected -- or a tridiagonal QL iteration that did not converge; the
+ * condition is reported once. */
 int sc_ctx_synchronize(sc_ctx* ctx);
 /* Library / device identification for logs: fills `buf` with e.g. "gfx950 AMD Instinct MI355X, 256 CUs". */
 int sc_device_info(sc_ctx* ctx, char* buf, size_t buflen);
@@ -180,7 +189,8 @@ int sc_anm_eigen_range_f64(sc_ctx* ctx, const double* coord, int64_t n_atoms, co
 
 /* ---- device-resident / batched entry points (bench + multi-structure sharding) ------------
  * All pointers are device pointers on the context's device.  Work is enqueued on the context's
- * stream; nothing synchronises unless stated. */
+ * stream; nothing synchronises (see the conventions at the top for the one exception and for
+ * how errors found on the device are reported). */
 
 /* d_coord: (batch, n_atoms, 3) f64.  d_matrix: (batch, dim*n_atoms, dim*n_atoms) f64, dim = 1
  * (Kirchhoff) or 3 (Hessian).  No patches on this path. d_inv_sqrt_mass: NULL or (batch, n_atoms). */

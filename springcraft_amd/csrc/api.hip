@@ -48,6 +48,55 @@ int sc_reserve_scratch(sc_ctx* ctx, size_t bytes) {
   return SC_OK;
 }
 
+int sc_stage_upload(sc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (bytes == 0) return SC_OK;
+  const int c = ctx->h_stage_cur;
+  if (ctx->h_stage_pending[c]) {   // this arena was last used two solves ago: its copies must have left it
+    SC_HIP(ctx, hipEventSynchronize(ctx->h_stage_done[c]));
+    ctx->h_stage_pending[c] = false;
+    ctx->h_stage_off[c] = 0;
+  }
+  const size_t need = align_up(ctx->h_stage_off[c] + bytes, 256);
+  if (need > ctx->h_stage_bytes[c]) {
+    // grow: copies of this solve may still be reading the old arena
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_stage[c]) SC_HIP(ctx, hipHostFree(ctx->h_stage[c]));
+    ctx->h_stage[c] = nullptr;
+    ctx->h_stage_bytes[c] = 0;
+    ctx->h_stage_off[c] = 0;
+    const size_t cap = std::max<size_t>(2 * need, (size_t)1 << 20);
+    SC_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage[c], cap, hipHostMallocDefault));
+    ctx->h_stage_bytes[c] = cap;
+  }
+  if (!ctx->h_stage_done[c]) SC_HIP(ctx, hipEventCreateWithFlags(&ctx->h_stage_done[c], hipEventDisableTiming));
+  char* slot = ctx->h_stage[c] + ctx->h_stage_off[c];
+  memcpy(slot, h_src, bytes);
+  ctx->h_stage_off[c] = align_up(ctx->h_stage_off[c] + bytes, 256);
+  SC_HIP(ctx, hipMemcpyAsync(d_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return SC_OK;
+}
+
+int sc_stage_end(sc_ctx* ctx) {
+  const int c = ctx->h_stage_cur;
+  if (!ctx->h_stage_done[c] || ctx->h_stage_off[c] == 0) return SC_OK;
+  SC_HIP(ctx, hipEventRecord(ctx->h_stage_done[c], ctx->stream));
+  ctx->h_stage_pending[c] = true;
+  ctx->h_stage_cur = 1 - c;
+  return SC_OK;
+}
+
+int sc_deferred_status(sc_ctx* ctx) {
+  if (!ctx->d_status) return SC_OK;
+  unsigned long long h[2] = {0, 0};
+  SC_HIP(ctx, hipMemcpy(h, ctx->d_status, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[0] == 0 && h[1] == 0) return SC_OK;
+  SC_HIP(ctx, hipMemset(ctx->d_status, 0, sizeof(h)));
+  if (h[0])   // np.linalg.eigh raises LinAlgError("Eigenvalues did not converge") for such input (nma.py:61)
+    return sc_set_error(ctx, SC_ERR_NOCONV, "Eigenvalues did not converge: matrix %llu of the batch contains NaN or Inf",
+                        h[0] - 1ull);
+  return sc_set_error(ctx, SC_ERR_NOCONV, "tridiagonal QL iteration did not converge");
+}
+
 int sc_reserve_pinv(sc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->pinv_ws_bytes) return SC_OK;
   if (ctx->pinv_ws) {
@@ -120,6 +169,12 @@ int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
     ctx->own_stream = true;
   } else {
     ctx->stream = (hipStream_t)stream;
+  }
+  if (hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_status, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SC_ERR_NOMEM;
   }
   *out = ctx;
   return SC_OK;
@@ -273,6 +328,11 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->dc_aux) (void)hipFree(ctx->dc_aux);
   if (ctx->pinv_ws) (void)hipFree(ctx->pinv_ws);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  for (int c = 0; c < 2; ++c) {
+    if (ctx->h_stage[c]) (void)hipHostFree(ctx->h_stage[c]);
+    if (ctx->h_stage_done[c]) (void)hipEventDestroy(ctx->h_stage_done[c]);
+  }
   if (ctx->aux_stream) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->aux_stream);
@@ -292,8 +352,9 @@ const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null c
 
 int sc_ctx_synchronize(sc_ctx* ctx) {
   if (!ctx) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SC_OK;
+  return sc_deferred_status(ctx);   // errors of the device-pointer solves enqueued since the last call
 }
 
 int sc_device_info(sc_ctx* ctx, char* buf, size_t buflen) {
@@ -596,7 +657,7 @@ int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, in
   if (!ctx) return SC_ERR_INVALID_ARG;
   if (n <= 0 || batch <= 0 || !d_a || !d_w) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
   SC_HIP(ctx, hipSetDevice(ctx->device));
-  return eigh_range_batched(ctx, d_a, n, batch, il, iu, d_w, d_v);
+  return eigh_range_batched_async(ctx, d_a, n, batch, il, iu, d_w, d_v);
 }
 
 static int enm_eigen_host(sc_ctx* ctx, const double* coord, int64_t n, const sc_ff_desc* ff,
@@ -668,7 +729,7 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
     return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
   SC_HIP(ctx, hipSetDevice(ctx->device));
   if (n == 0 || batch == 0) return SC_OK;
-  return eigh_batched(ctx, d_a, n, batch, d_w, d_v);
+  return eigh_batched_async(ctx, d_a, n, batch, d_w, d_v);
 }
 
 int sc_ctx_set_two_stage(sc_ctx* ctx, int mode) {

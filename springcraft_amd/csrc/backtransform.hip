@@ -217,7 +217,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       h[5 * grp + (size_t)p * batch + b] = Y;
     }
   }
-  SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
 
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
                      nref, off);
@@ -243,6 +243,5 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   }
   SC_HIP(ctx, hipGetLastError());
   t_w.finish(); t_u.finish();
-  SC_HIP(ctx, hipStreamSynchronize(st));  // `h` must outlive the descriptor upload
   return SC_OK;
 }

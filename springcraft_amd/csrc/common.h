@@ -40,6 +40,19 @@ struct sc_ctx {
   void* pinv_ws = nullptr;
   size_t pinv_ws_bytes = 0;
 
+  // host -> device uploads of descriptor tables without a stream synchronisation: the tables are copied into this
+  // pinned arena first (sc_stage_upload) and the arena is recycled once the event recorded at the end of the solve
+  // (sc_stage_end) has passed
+  // (two arenas taking turns, so that the host may enqueue solve k + 1 while solve k still runs)
+  char* h_stage[2] = {nullptr, nullptr};
+  size_t h_stage_bytes[2] = {0, 0}, h_stage_off[2] = {0, 0};
+  hipEvent_t h_stage_done[2] = {nullptr, nullptr};
+  bool h_stage_pending[2] = {false, false};
+  int h_stage_cur = 0;
+  // deferred status of the device-pointer eigensolver entries (which do not synchronise): [0] = 1 + index of a matrix
+  // with a NaN / Inf entry, [1] = the tridiagonal QL iteration failed.  Read and cleared by sc_deferred_status.
+  unsigned long long* d_status = nullptr;
+
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
   // persistent bulge chase (twostage.hip): chase_ok = 0 once a chase of this context ran into its time-out (never
   // expected; the per-wavefront launches take over from then on); chase_mode / chase_give_up are set through the debug
@@ -130,6 +143,13 @@ int sc_side_streams(sc_ctx* ctx, int count);   // makes sure side_streams / side
 int sc_reserve_scratch(sc_ctx* ctx, size_t bytes);
 int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes);
 int sc_reserve_pinv(sc_ctx* ctx, size_t bytes);
+// d_dst <- bytes at h_src, enqueued on ctx->stream; h_src may be released as soon as the call returns
+int sc_stage_upload(sc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+// end of a solve that used sc_stage_upload: the arena may be reused when everything enqueued so far has run
+int sc_stage_end(sc_ctx* ctx);
+// after a synchronisation of ctx->stream: SC_ERR_NOCONV (and the flags cleared) if a solve since the last call met
+// non-finite input or a QL failure, else SC_OK
+int sc_deferred_status(sc_ctx* ctx);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -176,11 +196,16 @@ int launch_assemble_items(sc_ctx* ctx, int dim, const void* d_items, int64_t cou
 
 // ---- eigensolver (eigh.hip and friends) ----------------------------------------------------
 // d_a: (batch, n, n) symmetric (destroyed), d_w: (batch, n), d_v: nullptr or (batch, n, n) rows = modes.
+// eigh_batched synchronises the stream and returns this solve's errors (host-pointer entry points); the _async form only
+// enqueues: non-finite input / a QL failure then surface through sc_deferred_status at the next synchronising call.
 int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
+int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v);
 size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors);
 // Partial spectrum: eigenvalues il..iu (0-based, inclusive): d_w (batch, m), d_v nullptr or (batch, m, n).
 int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
                        double* d_w, double* d_v);
+int eigh_range_batched_async(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
+                             double* d_w, double* d_v);
 // Hermitian pseudo-inverse of the (n,n) matrix d_a (destroyed) into d_out, numpy.linalg.pinv(hermitian=True) rule.
 int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n, double rcond, double* d_out);
 

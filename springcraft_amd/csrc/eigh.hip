@@ -175,7 +175,7 @@ size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors) {
   return make_plan(nullptr, (int)n, (int)batch, want_vectors).total;
 }
 
-int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double* d_w, double* d_v) {
+int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double* d_w, double* d_v) {
   if (n64 > 46000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "matrix order %lld too large", (long long)n64);
   const int n = (int)n64, batch = (int)batch64;
   const bool vectors = d_v != nullptr;
@@ -204,7 +204,7 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
       h[(size_t)p * batch + b] = D;
     }
   }
-  SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  SC_TRY(sc_stage_upload(ctx, descs, h.data(), h.size() * sizeof(GemmDesc)));
 
   ScopedEvents<4> ev;
   float ms_bt2 = 0.f;
@@ -282,14 +282,21 @@ int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double*
     if (P.two) ctx->last_timings[5] = vectors ? ms_bt2 : 1e-9;
     if (t_tf) t_tf->finish();
   }
-  SC_HIP(ctx, hipStreamSynchronize(st));  // host descriptor vectors must outlive their uploads
-  return SC_OK;
+  return sc_stage_end(ctx);   // (no synchronisation: the descriptor tables went through the context's pinned arena)
+}
+
+// Synchronising form for the host-pointer entry points: errors of THIS solve (non-finite input, QL failure) are
+// returned by it, as np.linalg.eigh raises them at nma.py:61.
+int eigh_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* d_w, double* d_v) {
+  SC_TRY(eigh_batched_async(ctx, d_a, n, batch, d_w, d_v));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return sc_deferred_status(ctx);
 }
 
 
 // ---- partial spectrum --------------------------------------------------------------------------------------
-int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, int64_t il64, int64_t iu64,
-                       double* d_w, double* d_v) {
+int eigh_range_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, int64_t il64, int64_t iu64,
+                             double* d_w, double* d_v) {
   if (n64 > 46000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "matrix order %lld too large", (long long)n64);
   const int n = (int)n64, batch = (int)batch64, il = (int)il64, iu = (int)iu64;
   if (il < 0 || iu < il || iu >= n)
@@ -359,7 +366,7 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
         h[(size_t)p * batch + b] = D;
       }
     }
-    SC_HIP(ctx, hipMemcpyAsync(descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+    SC_TRY(sc_stage_upload(ctx, descs, h.data(), h.size() * sizeof(GemmDesc)));
     SC_TRY(tridiag_batched(ctx, d_a, stride_a, n, batch, tri_ws, TL, descs, &ms_a, &ms_b));
   }
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
@@ -399,8 +406,14 @@ int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, i
     ctx->last_timings[4] = ms_b;
     ctx->last_timings[5] = two ? (d_v ? ms_bt2 : 1e-9) : 0.0;
   }
-  SC_HIP(ctx, hipStreamSynchronize(st));
-  return SC_OK;
+  return sc_stage_end(ctx);
+}
+
+int eigh_range_batched(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu, double* d_w,
+                       double* d_v) {
+  SC_TRY(eigh_range_batched_async(ctx, d_a, n, batch, il, iu, d_w, d_v));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return sc_deferred_status(ctx);
 }
 
 
@@ -444,9 +457,9 @@ int pinvh_device(sc_ctx* ctx, double* d_a, int64_t n64, double rcond, double* d_
     D.b = d_q; D.sb_k = n; D.sb_j = 1;        // U^T: B(k,j) = U[j, k]
     D.c = d_out; D.ldc = n; D.m = n; D.n = n; D.k = n;
     D.alpha = 1.0; D.beta = 0.0;
-    if (hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, st) != hipSuccess) rc = SC_ERR_HIP;
+    rc = sc_stage_upload(ctx, d_desc, &D, sizeof(D));
     if (rc == SC_OK) rc = launch_gemm_f64(ctx, d_desc, 1, n, n, kGemmTile, 1, false, false, kGemmAmBn);
-    if (hipStreamSynchronize(st) != hipSuccess && rc == SC_OK) rc = SC_ERR_HIP;   // D is a stack object
+    if (rc == SC_OK) rc = sc_stage_end(ctx);
   }
   return rc;
 }

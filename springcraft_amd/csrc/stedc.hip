@@ -721,10 +721,10 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   const size_t big_bytes = n > kLdsCapSetup ? (size_t)batch * 3 * n * sizeof(double) : 0;
   SC_TRY(sc_reserve_dc_aux(ctx, node_bytes + 256 + big_bytes));
   DcNode* d_nodes = reinterpret_cast<DcNode*>(ctx->dc_aux);
-  int* d_fail = reinterpret_cast<int*>(reinterpret_cast<char*>(d_nodes) + node_bytes);
+  // (a QL failure goes to the context's deferred status word, read at the next synchronising call)
+  int* d_fail = reinterpret_cast<int*>(ctx->d_status + 1);
   double* d_big = big_bytes ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_nodes) + node_bytes + 256) : nullptr;
-  SC_HIP(ctx, hipMemcpyAsync(d_nodes, flat.data(), flat.size() * sizeof(DcNode), hipMemcpyHostToDevice, st));
-  SC_HIP(ctx, hipMemsetAsync(d_fail, 0, sizeof(int), st));
+  SC_TRY(sc_stage_upload(ctx, d_nodes, flat.data(), flat.size() * sizeof(DcNode)));
 
   // eigenvector ping-pong: level l writes X[l+1]; X[nlev] must be d_q_out
   auto qbuf = [&](int stage) { return ((nlev - stage) % 2 == 0) ? d_q_out : d_q_tmp; };
@@ -759,9 +759,7 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
         }
       }
   }
-  if (!h_descs.empty())
-    SC_HIP(ctx, hipMemcpyAsync(d_merge_descs, h_descs.data(), h_descs.size() * sizeof(GemmDesc),
-                               hipMemcpyHostToDevice, st));
+  if (!h_descs.empty()) SC_TRY(sc_stage_upload(ctx, d_merge_descs, h_descs.data(), h_descs.size() * sizeof(GemmDesc)));
 
   hipLaunchKernelGGL(k_dc_prepare, dim3((unsigned)batch), dim3(1024), 0, st, d_tri_ws, TL, d_dc_ws, DL,
                      d_nodes + tree.leaves.size(), (int)n_internal);
@@ -820,10 +818,6 @@ int stedc_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                      d_dc_ws, DL, w_final, d_w, stride_w);
   SC_HIP(ctx, hipGetLastError());
 
-  int h_fail = 0;
-  SC_HIP(ctx, hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-  SC_HIP(ctx, hipStreamSynchronize(st));  // also keeps flat / h_descs alive until the copies are done
   t_gemm.finish();
-  if (h_fail) return sc_set_error(ctx, SC_ERR_NOCONV, "tridiagonal QL iteration did not converge");
   return SC_OK;
 }

@@ -336,7 +336,7 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
       U.alpha = 1.0; U.beta = 0.0;
       h[batch + b] = U;
     }
-    SC_HIP(ctx, hipMemcpyAsync(d_descs, h.data(), h.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+    SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
     SC_TRY(launch_gemm_f64(ctx, d_descs, batch, m, m, kGemmTile, splits, false, false, kGemmAkBk));
     {
       double* gram0 = d_ws + (size_t)6 * n * m;
@@ -344,7 +344,6 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
                          gram0 + (size_t)32 * m * m, stride_ws);
     }
     SC_TRY(launch_gemm_f64(ctx, d_descs + batch, batch, n, m, kGemmTile, 1, false, false, kGemmAmBk));
-    SC_HIP(ctx, hipStreamSynchronize(st));  // `h` is reused by the next round
     (void)x_cur;
   }
   t_qr.stop();

@@ -454,7 +454,8 @@ __global__ void k_mirror_lower(double* __restrict__ a_all, long long stride_a, i
 // by a power of two that brings it to ~1 (exact), and the eigenvalues are divided by it afterwards.  Everything is
 // decided on the device: amax -> factor -> conditional in-place scaling, no host synchronisation.
 __global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__ a_all, long long stride_a, int n,
-                                                      double* __restrict__ ws_all, TriLayout L) {
+                                                      double* __restrict__ ws_all, TriLayout L,
+                                                      unsigned long long* __restrict__ status) {
   const double* A = a_all + (size_t)blockIdx.y * stride_a;
   unsigned long long* slot = reinterpret_cast<unsigned long long*>(ws_all + (size_t)blockIdx.y * L.slab + L.hscale + 1);
   double m = 0.0;
@@ -472,9 +473,12 @@ __global__ __launch_bounds__(256) void k_absmax_lower(const double* __restrict__
   // the bit patterns of non-negative doubles are ordered like the values
   if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, (unsigned long long)__double_as_longlong(m));
   // a matrix with a NaN / Inf entry must not reach the solver (comparisons with NaN would drive its index arithmetic):
-  // its number + 1 goes to the flag in the FIRST matrix's slab, which prepare_matrix_batched reads back
-  if (__any(bad) && (threadIdx.x & 63) == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(ws_all + L.hscale + 3), (unsigned long long)blockIdx.y + 1ull);
+  // a flag in its own slab makes k_scale_lower replace it by the zero matrix and k_unscale_values return NaN for its
+  // eigenvalues; its number + 1 goes to the context's deferred status word (sc_deferred_status)
+  if (__any(bad) && (threadIdx.x & 63) == 0) {
+    *reinterpret_cast<unsigned long long*>(ws_all + (size_t)blockIdx.y * L.slab + L.hscale + 3) = 1ull;
+    atomicMax(status, (unsigned long long)blockIdx.y + 1ull);
+  }
 }
 
 __device__ __forceinline__ double matrix_scale_factor(double amax) {
@@ -487,23 +491,29 @@ __global__ __launch_bounds__(256) void k_scale_lower(double* __restrict__ a_all,
                                                      double* __restrict__ ws_all, TriLayout L) {
   double* ws = ws_all + (size_t)blockIdx.y * L.slab;
   const double amax = __longlong_as_double((long long)*reinterpret_cast<const unsigned long long*>(ws + L.hscale + 1));
-  const double f = matrix_scale_factor(amax);
-  if (blockIdx.x == 0 && threadIdx.x == 0) ws[L.hscale + 2] = f;
+  const bool bad = *reinterpret_cast<const unsigned long long*>(ws + L.hscale + 3) != 0ull;
+  const double f = bad ? 0.0 : matrix_scale_factor(amax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws[L.hscale + 2] = bad ? 1.0 : f;
   if (f == 1.0) return;
   double* A = a_all + (size_t)blockIdx.y * stride_a;
   const size_t total = (size_t)n * n;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
-    if (r >= c) A[idx] *= f;
+    if (r >= c) A[idx] = bad ? 0.0 : A[idx] * f;   // (a matrix with non-finite entries is solved as the zero matrix)
   }
 }
 
 __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_all, long long stride_w, int m,
                                                         const double* __restrict__ ws_all, TriLayout L) {
-  const double f = ws_all[(size_t)blockIdx.y * L.slab + L.hscale + 2];
-  if (f == 1.0) return;
+  const double* ws = ws_all + (size_t)blockIdx.y * L.slab;
+  const double f = ws[L.hscale + 2];
+  const bool bad = *reinterpret_cast<const unsigned long long*>(ws + L.hscale + 3) != 0ull;
+  if (f == 1.0 && !bad) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < m) w_all[(size_t)blockIdx.y * stride_w + i] /= f;
+  if (i < m) {
+    double& w = w_all[(size_t)blockIdx.y * stride_w + i];
+    w = bad ? __builtin_nan("") : w / f;
+  }
 }
 
 }  // namespace
@@ -523,15 +533,10 @@ int prepare_matrix_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, 
   for (int b = 0; b < batch; ++b)
     SC_HIP(ctx, hipMemsetAsync(d_tri_ws + (size_t)b * L.slab + L.hscale + 1, 0, 3 * sizeof(double), st));
   const unsigned gx = (unsigned)std::min<size_t>(1024, ((size_t)n * n + 255) / 256);
-  hipLaunchKernelGGL(k_absmax_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
-  unsigned long long h_bad = 0;
-  SC_HIP(ctx, hipMemcpyAsync(&h_bad, d_tri_ws + L.hscale + 3, sizeof(h_bad), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_absmax_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L,
+                     ctx->d_status);
   hipLaunchKernelGGL(k_scale_lower, dim3(gx, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, d_tri_ws, L);
   SC_HIP(ctx, hipGetLastError());
-  SC_HIP(ctx, hipStreamSynchronize(st));
-  if (h_bad)   // np.linalg.eigh raises LinAlgError("Eigenvalues did not converge") for such input (nma.py:61)
-    return sc_set_error(ctx, SC_ERR_NOCONV, "Eigenvalues did not converge: matrix %llu of the batch contains NaN or Inf",
-                        h_bad - 1ull);
   return SC_OK;
 }
 

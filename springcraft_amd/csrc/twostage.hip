@@ -1727,10 +1727,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       o[4 * batch + b] = g[4];
       o[5 * batch + b] = g[5];
     }
-  if (!hs.empty())
-    SC_HIP(ctx, hipMemcpyAsync(d_descs, hs.data(), hs.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, st));
+  if (!hs.empty()) SC_TRY(sc_stage_upload(ctx, d_descs, hs.data(), hs.size() * sizeof(GemmDesc)));
   const std::vector<int> doff = dia_offsets(n);
-  SC_HIP(ctx, hipMemcpyAsync(d_dia_off, doff.data(), doff.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  SC_TRY(sc_stage_upload(ctx, d_dia_off, doff.data(), doff.size() * sizeof(int)));
 
   // tau of columns without a reflector must read 0
   for (int b = 0; b < batch; ++b)
@@ -1960,7 +1959,6 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_HIP(ctx, hipEventElapsedTime(ms_stage2, ev[1], ev[2]));
   }
   t_qr.finish(); t_symm.finish(); t_syr2k.finish(); t_bulge.finish();
-  SC_HIP(ctx, hipStreamSynchronize(st));   // host descriptor vectors must outlive their uploads
   return SC_OK;
 }
 

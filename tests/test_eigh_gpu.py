@@ -422,3 +422,45 @@ def test_many_small_matrices_chunked_gemm_records(sc):
     for b in (0, batch // 2, batch - 1):
         w_ref = np.linalg.eigvalsh(keep[b].cpu().numpy())
         assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-12 * np.abs(w_ref).max()
+
+
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_device_entry_points_do_not_synchronise_and_defer_errors(two_stage):
+    """
+    sc_dev_eigh_f64 only enqueues (its descriptor tables go through the context's pinned staging arena): a matrix with
+    a NaN in a batch is solved as the zero matrix, its eigenvalues come back NaN, the other matrices of the batch are
+    unaffected, and the error surfaces as LinAlgError (what np.linalg.eigh raises, nma.py:61) at the next
+    sc_ctx_synchronize -- once.
+    """
+    import ctypes as C
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    n, batch = 700, 5
+    rs = np.random.RandomState(9)
+    mats = np.stack([(lambda a: a + a.T)(rs.standard_normal((n, n))) for _ in range(batch)])
+    mats[3, 400, 20] = np.nan          # lower triangle of matrix 3
+    L = _hip.lib()
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_two_stage(two_stage)
+        # (the context has a stream of its own: inputs are prepared on torch's stream and synchronised first)
+        inputs = [torch.from_numpy(mats.copy()).cuda() for _ in range(2)]
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for a in inputs:               # two solves back to back without a synchronisation in between
+            ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                        C.c_void_p(v.data_ptr())))
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.synchronize()
+        ctx.synchronize()              # the flag is cleared by the call that reported it
+        wh = w.cpu().numpy()
+        assert np.isnan(wh[3]).all()
+        for b in (0, 1, 2, 4):
+            w_ref = np.linalg.eigvalsh(mats[b])
+            assert np.abs(wh[b] - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.close()
