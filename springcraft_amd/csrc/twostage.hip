@@ -1334,7 +1334,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   int fin_row = 0;
   bool have_fin = false;
   BT2_STAMP_DECL
-  int S_cur = 0;
+  int S_cur = 0;   // (read by the -DBT2_TRACE build only)
+  (void)S_cur;
   auto diamond = [&](auto PH, const double* fgrp, int k, int nh, bool more, int& slot, int win) {
     constexpr int ph = decltype(PH)::value;
 #ifdef BT2_TRACE
