@@ -18,7 +18,7 @@
  *     and only enqueue work on the context's stream: descriptor tables travel through a pinned
  *     staging arena of the context, and what a solve can only find out on the device (a NaN / Inf
  *     entry in an input matrix, a failed QL iteration) is reported by the next sc_ctx_synchronize.
- *     One exception: a two-stage solve of a latency-bound batch (batch * n / 128 <= 1200) waits for
+ *     One exception: a two-stage solve of a latency-bound batch (batch * n / 128 <= 2800) waits for
  *     its persistent bulge chase, whose control block decides whether the chase is complete;
  *   - all matrices are float64; Kirchhoff is (n,n), Hessian (3n,3n), C order, exactly as
  *     numpy returns them in the reference (interaction.py:48,107-109);

@@ -782,11 +782,21 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 // per XCD, [10..12] (matrix, sweep, task) of the wait that timed out, [16..23] sweeps finished per XCD.
 constexpr int kChaseCtlInts = 32;
 
-__device__ __forceinline__ double ld_l2(const double* p) {
+typedef double __attribute__((address_space(1)))* gdptr;          // global memory: global_load / global_store, never flat
+typedef const double __attribute__((address_space(1)))* gdptr_c;
+__device__ __forceinline__ double ld_l2(gdptr_c p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a pointer every lane of the wave holds the same value of, told so to the compiler (scalar registers, and memory
+// instructions of the form scalar base + 32-bit lane offset instead of a 64-bit address per access)
+__device__ __forceinline__ gdptr wave_uniform(double* p) {
+  const unsigned long long b = (unsigned long long)(size_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return (gdptr)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 
-__global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
+__global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
                                                      int* __restrict__ ctl, int give_up_after) {
   constexpr int LD = kB + 1;
@@ -820,7 +830,7 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
     // ---- claim the next sweep of matrix b (the counter is only ever touched from this XCD)
     if (tid == 0) s_claim = atomicAdd(next_sweep + b, 1);
     __syncthreads();
-    const int s = s_claim;
+    const int s = __builtin_amdgcn_readfirstlane(s_claim);
     __syncthreads();
     if (s > n - 3) {
       ++exhausted;
@@ -867,22 +877,25 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         const int L = min(kB, n - r0);
         const size_t dia = dia0 + k;
         double* vd = sb + SL.vd + dia * kDiaSize + (size_t)cc * kG + cc;
+        // (one wave-uniform base per block + 32-bit element offsets: a 64-bit pointer per access costs the kernel a
+        // workgroup per CU in registers)
+        gdptr colbase_k = wave_uniform(ab + (size_t)r0 * kLdab);                 // AB(r0, r0)
         double d16[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const int jc = min(q * 16 + c, L - 1);
           const int ic = min(max(i, jc), L - 1);
-          d16[c] = ld_l2(ab + (size_t)(ic - jc) + (size_t)(r0 + jc) * kLdab);
+          d16[c] = ld_l2(colbase_k + (unsigned)((ic - jc) + jc * kLdab));
         }
         if (k > 0) {
-          const int c0 = r0 - kB;
+          gdptr ebase_k = wave_uniform(ab + (size_t)(r0 - kB) * kLdab);          // AB(r0 - kB, r0 - kB)
           double t16[16];
           {
             const int ic = min(i, L - 1);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
               const int jj = q * 16 + c;
-              t16[c] = ld_l2(ab + (size_t)(kB + ic - jj) + (size_t)(c0 + jj) * kLdab);
+              t16[c] = ld_l2(ebase_k + (unsigned)((kB + ic - jj) + jj * kLdab));
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) t16[c] = i < L ? t16[c] : 0.0;
@@ -924,17 +937,18 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
             const int jj = q * 16 + c;
             double e = t16[c] - vn[i] * u[jj];
             if (jj == 0) e = i == 0 ? s_beta : 0.0;
-            if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
+            if (i < L) ebase_k[(unsigned)((kB + i - jj) + jj * kLdab)] = e;
           }
         } else {
           if (tid < 64) {
-            const double xr = ld_l2(ab + (size_t)(1 + min(tid, L - 1)) + (size_t)s * kLdab);
+            gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
+            const double xr = ld_l2(col_s + (unsigned)(1 + min(tid, L - 1)));
             const double x = tid < L ? xr : 0.0;
             const double t2 = wave_sum(tid >= 1 ? x * x : 0.0);
             const HH h = householder(__shfl(x, 0), t2);
             vn[tid] = tid == 0 ? 1.0 : x * h.scale;
             if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
-            if (tid < L) ab[(size_t)(1 + tid) + (size_t)s * kLdab] = tid == 0 ? h.beta : 0.0;
+            if (tid < L) col_s[(unsigned)(1 + tid)] = tid == 0 ? h.beta : 0.0;
           }
           lds_barrier();
         }
@@ -965,7 +979,7 @@ __global__ __launch_bounds__(256) void k_bulge_chase(double* __restrict__ sb_all
         lds_barrier();
         for (int jj = q * 16; jj < q * 16 + 16; ++jj)
           if (i >= jj && i < L)
-            ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
+            colbase_k[(unsigned)((i - jj) + jj * kLdab)] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
         if (tid < L) vd[(size_t)tid * kG] = vn[tid];
         if (tid == 0) sb[SL.tau2 + dia * kG + cc] = tau_now;
         tau_p = tau_now;
@@ -1845,12 +1859,13 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     static const int env_persist = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PERSISTENT"); return e ? atoi(e) : 1; }();
     const int persist = ctx->chase_mode >= 0 ? ctx->chase_mode : env_persist;
     bool chased = false;
-    // it pays while a wavefront's tasks fit the chip about once: measured crossover batch * n / 128 ~ 1200
-    // (tools/bulge_sweep.py); beyond that the per-wavefront launches on two streams are faster and, with fewer matrices
-    // than XCDs (a matrix is confined to one XCD), only while the order is moderate: a single n = 12000 matrix chases
-    // 1.5 x faster with its ~94 tasks per wavefront spread over the whole chip
+    // it pays while the stage is latency-bound: measured crossover batch * n / 128 ~ 2800 (tools/bulge_sweep.py,
+    // profiles/r03_bulge_sweep.txt: 32 x n = 6000 195 vs 253 ms, 64 x n = 6000 a tie at 436; round 2, with one workgroup
+    // per CU for want of registers: ~ 1200); beyond that the per-wavefront launches on several streams take over.  With
+    // fewer matrices than XCDs (a matrix is confined to one XCD) only while the order is moderate: a single n = 24000
+    // matrix chases 1.6 x faster with its ~188 tasks per wavefront spread over the whole chip (411 vs 676 ms)
     const bool want_chase =
-        persist == 2 || (persist == 1 && (long long)batch * n / 128 <= 1200 && (batch >= 8 || n <= 6144));
+        persist == 2 || (persist == 1 && (long long)batch * n / 128 <= 2800 && (batch >= 8 || n <= 6144));
     // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):
     // every further attempt could cost another bound's worth of spinning before the fallback
     if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
