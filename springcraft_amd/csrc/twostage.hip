@@ -586,8 +586,22 @@ __device__ unsigned long long g_bulge_stamps[8];
 #define BULGE_STAMP(var)
 #endif
 
+typedef double __attribute__((address_space(1)))* gdptr;          // global memory: global_load / global_store, never flat
+typedef const double __attribute__((address_space(1)))* gdptr_c;
+__device__ __forceinline__ double ld_l2(gdptr_c p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a pointer every lane of the wave holds the same value of, told so to the compiler (scalar registers, and memory
+// instructions of the form scalar base + 32-bit lane offset instead of a 64-bit address per access)
+__device__ __forceinline__ gdptr wave_uniform(double* p) {
+  const unsigned long long b = (unsigned long long)(size_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return (gdptr)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
 // Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
-__global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
+__global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
                                                     int t, const int* __restrict__ done = nullptr) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
@@ -617,16 +631,18 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 
   // the diagonal block D = AB(r0 .. r0+L-1, r0 .. r0+L-1) (lower stored) is not touched before its own update:
   // fetch it right away (unconditional loads with clamped indices, masked when they go to LDS)
+  // (one wave-uniform base per block + 32-bit element offsets instead of a 64-bit address per access)
+  gdptr colbase = wave_uniform(ab + (size_t)r0 * kLdab);                    // AB(r0, r0)
   double d16[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int jc = std::min(q * 16 + u, L - 1);
     const int ic = std::min(std::max(i, jc), L - 1);
-    d16[u] = ab[(size_t)(ic - jc) + (size_t)(r0 + jc) * kLdab];
+    d16[u] = colbase[(unsigned)((ic - jc) + jc * kLdab)];
   }
 
   if (k > 0) {
-    const int c0 = r0 - kB;
+    gdptr ebase = wave_uniform(ab + (size_t)(r0 - kB) * kLdab);             // AB(r0 - kB, r0 - kB)
     const double* vdp = sb + SL.vd + (dia - 1) * kDiaSize + (size_t)cc * kG + cc;
     const double tau_p = sb[SL.tau2 + (dia - 1) * kG + cc];
     if (tid < kB) vp[tid] = vdp[(size_t)tid * kG];
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int jj = q * 16 + u;
-        t16[u] = ab[(size_t)(kB + ic - jj) + (size_t)(c0 + jj) * kLdab];
+        t16[u] = ebase[(unsigned)((kB + ic - jj) + jj * kLdab)];
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) t16[u] = i < L ? t16[u] : 0.0;
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
       const int jj = q * 16 + c;
       double e = t16[c] - vn[i] * u[jj];
       if (jj == 0) e = i == 0 ? s_beta : 0.0;
-      if (i < L) ab[(size_t)(kB + i - jj) + (size_t)(c0 + jj) * kLdab] = e;
+      if (i < L) ebase[(unsigned)((kB + i - jj) + jj * kLdab)] = e;
     }
 #ifdef BULGE_STAMPS
     { BULGE_STAMP(t2) if (tid == 0) { atomicAdd(&g_bulge_stamps[1], t2 - t0); atomicAdd(&g_bulge_stamps[5], 1ull); } }
@@ -737,7 +753,7 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
   lds_barrier();
   for (int jj = q * 16; jj < q * 16 + 16; ++jj)
     if (i >= jj && i < L)
-      ab[(size_t)(i - jj) + (size_t)(r0 + jj) * kLdab] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
+      colbase[(unsigned)((i - jj) + jj * kLdab)] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
 
   // the reflector goes into its diamond
   if (tid < L) vd[(size_t)tid * kG] = vn[tid];
@@ -782,19 +798,6 @@ __global__ __launch_bounds__(256) void k_bulge_step(double* __restrict__ sb_all,
 // per XCD, [10..12] (matrix, sweep, task) of the wait that timed out, [16..23] sweeps finished per XCD.
 constexpr int kChaseCtlInts = 32;
 
-typedef double __attribute__((address_space(1)))* gdptr;          // global memory: global_load / global_store, never flat
-typedef const double __attribute__((address_space(1)))* gdptr_c;
-__device__ __forceinline__ double ld_l2(gdptr_c p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// a pointer every lane of the wave holds the same value of, told so to the compiler (scalar registers, and memory
-// instructions of the form scalar base + 32-bit lane offset instead of a 64-bit address per access)
-__device__ __forceinline__ gdptr wave_uniform(double* p) {
-  const unsigned long long b = (unsigned long long)(size_t)p;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-  return (gdptr)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
 
 __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
