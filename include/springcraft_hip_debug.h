@@ -16,8 +16,8 @@ extern "C" {
 
 /* Times `iters` launches of one grouped-GEMM shape on buffers it allocates itself and checks the result against a host
  * product (max abs error).  mode 0: C = A B (A m x k, B k x n, column-major); 1: lower triangle of C += A B^T (the
- * SYR2K shape, B stored n x k); 2: C = A^T B (A stored k x m).  tile 0..3 pick the round-1 kernel's tilings,
- * 10..13 the k_gemm2 tilings (automatic, 128x128, 128x64, 64x64).  Returns an SC_* code.  tools/gemm2_bench.py */
+ * SYR2K shape, B stored n x k); 2: C = A^T B (A stored k x m).  tile 10..13: the k_gemm2 tilings (automatic,
+ * 128x128, 128x64, 64x64).  Returns an SC_* code.  tools/gemm2_bench.py */
 int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int split_k, int iters, int beta_one,
                       double* ms_out, double* max_err_out);
 

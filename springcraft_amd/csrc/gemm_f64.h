@@ -33,21 +33,18 @@ struct GemmDesc {
   int a_tri;              // launches with tri = true: 1: A(i,k) counts only for i >= k; 2: only for k > i
 };
 
-// Default block tile of the solver's GEMMs: 64 x 64 x 8 (tile id 3).  On gfx950 the f64 MFMA is slow enough
-// (64+ cycles per 16x16x4) that operand traffic is never the limit; what pays is occupancy — 3-5 resident
-// workgroups per CU whose load / MFMA / store phases overlap.  Measured (profiles/r01_gemm_shapes.txt):
-// 6000^3 43 TFLOP/s vs 33 with 128x128x16 tiles; SYR2K K=128 27 vs 18; K=256 32 vs 22.
+// (`tile` argument of launch_gemm_f64: a leftover of round 1's kernel, ignored; k_gemm2 picks its block tile from the
+// launch size)
 constexpr int kGemmTile = 3;
 
 // Launch `count` problems (records d_desc[0..count)); max_m / max_n bound the grid.
-// tile: 0 = 128x128x16 block tile, 1 = 64x128x16, 2 = 64x64x16, 3 = 64x64x8 (see kGemmTile).
+// tile: ignored (see kGemmTile).
 // split_k > 1: every record is cut into split_k K-slices (all records of a launch share it).
-// gather: the records carry a_kidx / b_kidx lists (D&C merges); uses the 64x64x8 tile whatever `tile` says.
-// tri: the records carry a_tri masks (lower-stored symmetric A; band reduction); 64x64x8 tile, no gathers.
-// layout: which axis of each operand has stride 1 in ALL records of the launch (the records live in device memory, the
-// host cannot look): kGemmAmBk "NN" (sa_i = 1, sb_k = 1), kGemmAkBk "TN" (sa_k = 1, sb_k = 1), kGemmAmBn "NT"
-// (sa_i = 1, sb_j = 1).  Launches that state it (and carry no gather lists) run the MFMA-paced k_gemm2 with a block
-// tile chosen from the launch size; -1 (unknown) runs the older stride-agnostic kernel with the `tile` asked for.
+// gather: the records carry a_kidx / b_kidx lists (D&C merges; layout kGemmAmBk only).
+// tri: the records carry a_tri masks (lower-stored symmetric A; band reduction; layouts kGemmAmBk / kGemmAkBk), no gathers.
+// layout (required): which axis of each operand has stride 1 in ALL records of the launch (the records live in device
+// memory, the host cannot look): kGemmAmBk "NN" (sa_i = 1, sb_k = 1), kGemmAkBk "TN" (sa_k = 1, sb_k = 1), kGemmAmBn
+// "NT" (sa_i = 1, sb_j = 1).  The block tile is chosen from the launch size.
 // lower_grid: every record of the launch is square, lower_only with row_off = col_off = 0 (the SYR2K of the band
 // reduction): only the tiles on and below the diagonal are launched (layout kGemmAmBn, no split-K).
 constexpr int kGemmAmBk = 0, kGemmAkBk = 1, kGemmAmBn = 2;

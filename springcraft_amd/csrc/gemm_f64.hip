@@ -1,17 +1,6 @@
 // float64 GEMM on the CDNA4 matrix cores — see gemm_f64.h for the contract.
-//
-// Block tile BM x 128 (BM = 128 or 64), K step 16, 256 threads = 4 waves arranged 2 x 2, each wave
-// owning a (BM/2) x 64 sub-tile built from v_mfma_f64_16x16x4_f64 tiles (64 lanes x 4 f64 results).
-// Two blocks per CU = 2 waves per SIMD, >= 8 independent accumulators per wave: the regime in which
-// the f64 MFMA pipe reached its practical ceiling in profiles/r01_probe_f64.txt (47 TFLOP/s).
-//
-// Operand staging: global -> registers (next K step, issued before the MFMAs of the current step)
-// -> LDS [k][m|n] double-buffered, one barrier per K step.  LDS rows are padded to tile+16 doubles
-// so the four k-rows a ds_read_b64 wave-instruction touches fall on disjoint banks.
-//
-// The MFMA is fed "swapped" (its A operand comes from the B tile, its B operand from the A tile):
-// the accumulator then holds C^T fragments whose 16 consecutive lanes map to 16 consecutive ROWS
-// of the column-major C, so C loads / stores are 128-byte contiguous segments.
+// (Round 1's stride-agnostic 64 x 64 x 8 kernel, kept behind switches through round 2 for A/B runs, is gone: every launch
+// of the solver states its operand layout and runs k_gemm2.)
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -23,223 +12,8 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int PAD = 16;
-
-template <int BM, int BN, int BK, int MINW, bool GATHER, bool TRI = false>
-__global__ __launch_bounds__(256, MINW) void k_gemm_f64(const GemmDesc* __restrict__ descs, int split_k) {
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
-  constexpr int A_PER_THREAD = BM * BK / 256, B_PER_THREAD = BN * BK / 256;
-
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sA = smem;                        // [2][BK][LDA_S]
-  double* sB = smem + 2 * BK * LDA_S;       // [2][BK][LDB_S]
-
-  const int z = blockIdx.z;
-  const int slice = split_k > 1 ? z % split_k : 0;
-  const GemmDesc& D = descs[split_k > 1 ? z / split_k : z];
-  const int M = D.m, N = D.n, K = D.k;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (m0 >= M || n0 >= N) return;   // K == 0 still runs: it stores beta*C (zeros for beta = 0)
-  if (D.lower_only && (m0 + BM - 1 + D.row_off) < (n0 + D.col_off)) return;
-
-  int k_begin = 0, k_end = K;
-  if (split_k > 1) {
-    const int chunk = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
-    k_begin = slice * chunk;
-    k_end = min(K, k_begin + chunk);
-  }
-  // triangular A operand (TRI instantiation, the symmetric products of the band reduction): the block only walks
-  // the K range in which its rows have non-zero entries
-  const int tri = TRI ? D.a_tri : 0;
-  if (TRI && tri == 1) k_end = min(k_end, m0 + BM);
-  if (TRI && tri == 2) k_begin = max(k_begin, m0);
-
-  const double* __restrict__ A = D.a;
-  const double* __restrict__ B = D.b;
-  const long long sa_i = D.sa_i, sa_k = D.sa_k, sb_k = D.sb_k, sb_j = D.sb_j;
-  // gather lists are only looked at by the GATHER instantiation (the D&C merges); the plain one pays nothing
-  const int* __restrict__ kidx = GATHER ? D.a_kidx : nullptr;
-  const int* __restrict__ bkidx = GATHER ? D.b_kidx : nullptr;
-  const bool a_mcontig = (sa_i == 1);
-  const bool b_ncontig = (sb_j == 1);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-
-  double ra[A_PER_THREAD], rb[B_PER_THREAD];
-
-  auto load_tiles = [&](int kt) {
-    // A tile: BM x BK
-    if (a_mcontig) {
-      const int i = tid % BM, kq = tid / BM;
-      constexpr int KSTEP = 256 / BM;
-#pragma unroll
-      for (int p = 0; p < A_PER_THREAD; ++p) {
-        const int k = kt + kq + p * KSTEP;
-        const int gi = m0 + i;
-        double v = 0.0;
-        if (gi < M && k < k_end && (!TRI || tri == 0 || (tri == 1 ? gi >= k : k > gi))) {
-          const long long kk = (GATHER && kidx) ? (long long)kidx[k] : (long long)k;
-          v = A[(long long)gi + kk * sa_k];
-        }
-        ra[p] = v;
-      }
-    } else {
-      const int k = tid % BK, iq = tid / BK;
-      constexpr int ISTEP = 256 / BK;
-#pragma unroll
-      for (int p = 0; p < A_PER_THREAD; ++p) {
-        const int gi = m0 + iq + p * ISTEP;
-        const int gk = kt + k;
-        ra[p] = (gi < M && gk < k_end && (!TRI || tri == 0 || (tri == 1 ? gi >= gk : gk > gi)))
-                    ? A[(long long)gi * sa_i + gk] : 0.0;
-      }
-    }
-    // B tile: BK x BN
-    if (b_ncontig) {
-      const int j = tid % BN, kq = tid / BN;
-      constexpr int KSTEP = 256 / BN;
-#pragma unroll
-      for (int p = 0; p < B_PER_THREAD; ++p) {
-        const int k = kt + kq + p * KSTEP;
-        const int gj = n0 + j;
-        double v = 0.0;
-        if (gj < N && k < k_end) v = B[((GATHER && bkidx) ? (long long)bkidx[k] : (long long)k) * sb_k + gj];
-        rb[p] = v;
-      }
-    } else {
-      const int k = tid % BK, jq = tid / BK;
-      constexpr int JSTEP = 256 / BK;
-#pragma unroll
-      for (int p = 0; p < B_PER_THREAD; ++p) {
-        const int gj = n0 + jq + p * JSTEP;
-        const int gk = kt + k;
-        double v = 0.0;
-        if (gj < N && gk < k_end)
-          v = B[((GATHER && bkidx) ? (long long)bkidx[gk] : (long long)gk) + (long long)gj * sb_j];
-        rb[p] = v;
-      }
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-    double* a_s = sA + buf * BK * LDA_S;
-    double* b_s = sB + buf * BK * LDB_S;
-    if (a_mcontig) {
-      const int i = tid % BM, kq = tid / BM;
-      constexpr int KSTEP = 256 / BM;
-#pragma unroll
-      for (int p = 0; p < A_PER_THREAD; ++p) a_s[(kq + p * KSTEP) * LDA_S + i] = ra[p];
-    } else {
-      const int k = tid % BK, iq = tid / BK;
-      constexpr int ISTEP = 256 / BK;
-#pragma unroll
-      for (int p = 0; p < A_PER_THREAD; ++p) a_s[k * LDA_S + iq + p * ISTEP] = ra[p];
-    }
-    if (b_ncontig) {
-      const int j = tid % BN, kq = tid / BN;
-      constexpr int KSTEP = 256 / BN;
-#pragma unroll
-      for (int p = 0; p < B_PER_THREAD; ++p) b_s[(kq + p * KSTEP) * LDB_S + j] = rb[p];
-    } else {
-      const int k = tid % BK, jq = tid / BK;
-      constexpr int JSTEP = 256 / BK;
-#pragma unroll
-      for (int p = 0; p < B_PER_THREAD; ++p) b_s[k * LDB_S + jq + p * JSTEP] = rb[p];
-    }
-  };
-
-  d4 acc[NT][MT];
-  const int fr = lane & 15, fk = lane >> 4;
-
-  // C(row = m0 + wm*WM + mi*16 + fr, col = n0 + wn*WN + ni*16 + fk + 4r) <-> acc[ni][mi][r]
-  double* __restrict__ C = D.c + (split_k > 1 ? (long long)slice * D.split_stride : 0LL);
-  const double alpha = D.alpha;
-  const double beta = split_k > 1 ? 0.0 : D.beta;
-  const long long ldc = D.ldc;
-  const int* __restrict__ jidx = D.c_jidx;
-  const bool lower = D.lower_only != 0;
-  const int roff = D.row_off, coff = D.col_off;
-
-  load_tiles(k_begin);
-  // beta * C goes straight into the accumulators (scaled by 1/alpha), its loads in flight together with
-  // the first operand tiles: the epilogue is then store-only.
-  if (beta != 0.0 && alpha != 0.0) {
-    const double scale = beta / alpha;
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
-        const long long dcol = (jidx && col < N) ? (long long)jidx[col] : (long long)col;
-        const double* ccol = C + dcol * ldc;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int row = m0 + wm * WM + mi * 16 + fr;
-          double v = 0.0;
-          if (col < N && row < M && !(lower && (row + roff) < (col + coff))) v = ccol[row] * scale;
-          acc[ni][mi][r] = v;
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = d4{0.0, 0.0, 0.0, 0.0};
-  }
-  store_tiles(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = k_begin; kt < k_end; kt += BK) {
-    const bool has_next = kt + BK < k_end;
-    if (has_next) load_tiles(kt + BK);
-    const double* a_s = sA + buf * BK * LDA_S;
-    const double* b_s = sB + buf * BK * LDB_S;
-#pragma unroll
-    for (int k4 = 0; k4 < BK / 4; ++k4) {
-      double af[MT], bf[NT];
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) af[mi] = a_s[(k4 * 4 + fk) * LDA_S + wm * WM + mi * 16 + fr];
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni) bf[ni] = b_s[(k4 * 4 + fk) * LDB_S + wn * WN + ni * 16 + fr];
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    }
-    if (has_next) store_tiles(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  // ---- epilogue (store only)
-#pragma unroll
-  for (int ni = 0; ni < NT; ++ni) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = n0 + wn * WN + ni * 16 + fk + 4 * r;
-      if (col >= N) continue;
-      const long long dcol = jidx ? (long long)jidx[col] : (long long)col;
-      double* ccol = C + dcol * ldc;
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        const int row = m0 + wm * WM + mi * 16 + fr;
-        if (row >= M) continue;
-        if (lower && (row + roff) < (col + coff)) continue;
-        ccol[row] = alpha * acc[ni][mi][r];
-      }
-    }
-  }
-}
-
-
 // ================================================================================================================
-// k_gemm2: the MFMA-paced kernel used for every launch without gather lists.
+// k_gemm2: the MFMA-paced kernel behind every launch.
 //
 // The f64 matrix pipe issues one v_mfma_f64_16x16x4_f64 per 64 cycles per SIMD at the 2.4 GHz the chip holds under this
 // load (profiles/r02_probe_clock.txt: 78 TFLOP/s, the datasheet rate), so what a GEMM has to do is keep that pipe
@@ -653,10 +427,6 @@ void launch_gemm2_layout(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int 
 
 namespace {
 int g_gemm2_force_tile = 0;   // debugging (sc_dbg_gemm_bench): 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64
-bool gemm2_enabled() {
-  static const bool on = getenv("SPRINGCRAFT_GEMM_OLD") == nullptr;
-  return on;
-}
 // block tile of k_gemm2: 128-wide in a dimension when the problem is at least that wide there and the launch still has
 // >= 2 workgroups per CU (lower-only launches: about half of the square grid does work)
 void gemm2_tile(const sc_ctx* ctx, int count, int max_m, int max_n, int split_k, int layout, int* bm, int* bn) {
@@ -693,8 +463,7 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
     return SC_OK;
   }
   hipStream_t st = ctx->stream;
-  static const bool gather_old = getenv("SPRINGCRAFT_GEMM_GATHER_OLD") != nullptr;
-  if (gather && !tri && layout == kGemmAmBk && gemm2_enabled() && !gather_old) {
+  if (gather && !tri && layout == kGemmAmBk) {
     // merges of the divide & conquer: 128 x 64 tiles while they fill the chip, else 64 x 64
     const long long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const long long gz = (long long)count * split_k;
@@ -707,7 +476,7 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
   }
-  if (!gather && layout >= 0 && layout <= 2 && !(tri && layout == kGemmAmBn) && gemm2_enabled()) {
+  if (!gather && layout >= 0 && layout <= 2 && !(tri && layout == kGemmAmBn)) {
     int bm, bn;
     gemm2_tile(ctx, count, max_m, max_n, split_k, layout, &bm, &bn);
     const long long gz = (long long)count * split_k;
@@ -726,35 +495,9 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
   }
-  // gather / tri launches always run the 64 x 64 x 8 instantiation: size the grid and the LDS for that tile; so does any
-  // tile id this kernel does not have (the k_gemm2 ids 10 .. 13 of the debug entry points when k_gemm2 is switched off)
-  if (gather || tri || tile < 0 || tile > 3) tile = 3;
-  const int bm = tile == 0 ? 128 : 64;
-  const int bn = (tile == 2 || tile == 3) ? 64 : 128;
-  const int bk = tile == 3 ? 8 : 16;
-  // grid.z is limited to 65535: launch in chunks of records
-  const int max_rec = 65535 / split_k;
-  if (max_rec < 1) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "split_k %d too large", split_k);
-  const size_t lds = sizeof(double) * 2 * bk * ((size_t)(bm + PAD) + (bn + PAD));
-  for (int r0 = 0; r0 < count; r0 += max_rec) {
-    const int cnt = std::min(max_rec, count - r0);
-    const GemmDesc* dd = d_desc + r0;
-    dim3 grid((unsigned)((max_m + bm - 1) / bm), (unsigned)((max_n + bn - 1) / bn), (unsigned)(cnt * split_k));
-    if (tri)
-      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false, true>), grid, dim3(256), lds, st, dd, split_k);
-    else if (gather)
-      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, true>), grid, dim3(256), lds, st, dd, split_k);
-    else if (tile == 1)
-      hipLaunchKernelGGL((k_gemm_f64<64, 128, 16, 2, false>), grid, dim3(256), lds, st, dd, split_k);
-    else if (tile == 2)
-      hipLaunchKernelGGL((k_gemm_f64<64, 64, 16, 4, false>), grid, dim3(256), lds, st, dd, split_k);
-    else if (tile == 3)
-      hipLaunchKernelGGL((k_gemm_f64<64, 64, 8, 4, false>), grid, dim3(256), lds, st, dd, split_k);
-    else
-      hipLaunchKernelGGL((k_gemm_f64<128, 128, 16, 2, false>), grid, dim3(256), lds, st, dd, split_k);
-  }
-  SC_HIP(ctx, hipGetLastError());
-  return SC_OK;
+  (void)tile;
+  return sc_set_error(ctx, SC_ERR_INVALID_ARG, "GEMM launch without a supported operand layout (layout %d, gather %d, tri %d)",
+                      layout, (int)gather, (int)tri);
 }
 
 extern "C" int sc_dbg_gemm_stamps(unsigned long long* out4, int reset) {
@@ -820,9 +563,10 @@ extern "C" int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int
   if (mode == 2) { D.sa_i = k; D.sa_k = 1; D.sb_k = 1; D.sb_j = k; }
   D.split_stride = (long long)m * n;
   SC_HIP(ctx, hipMemcpy(dd, &D, sizeof(D), hipMemcpyHostToDevice));
-  // tile 10 .. 13: k_gemm2 (10: automatic block tile, 11: 128 x 128, 12: 128 x 64, 13: 64 x 64); else the old kernel
-  const int layout = tile >= 10 ? (mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk)) : -1;
-  g_gemm2_force_tile = tile >= 10 ? tile - 10 : 0;
+  // tile 10 .. 13: k_gemm2 (10: automatic block tile, 11: 128 x 128, 12: 128 x 64, 13: 64 x 64)
+  if (tile < 10 || tile > 13) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "tile id %d (10 .. 13)", tile);
+  const int layout = mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk);
+  g_gemm2_force_tile = tile - 10;
   SC_TRY(launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, mode == 1 && m == n));
   SC_HIP(ctx, hipStreamSynchronize(st));
   // spot check 64 entries against a host dot product (beta path: C was 0 before the first launch)
@@ -887,10 +631,14 @@ extern "C" int sc_dbg_gemm_host(sc_ctx* ctx, const double* a, const double* b, d
   D.split_stride = (long long)m * n;
   fail(hipMemcpy(dd, &D, sizeof(D), hipMemcpyHostToDevice));
   if (rc == SC_OK) {
-    const int layout = tile >= 10 ? (mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk)) : -1;
-    g_gemm2_force_tile = tile >= 10 ? tile - 10 : 0;
-    rc = launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, lower_grid != 0);
-    g_gemm2_force_tile = 0;
+    const int layout = mode == 0 ? kGemmAmBk : (mode == 1 ? kGemmAmBn : kGemmAkBk);
+    if (tile < 10 || tile > 13) {
+      rc = sc_set_error(ctx, SC_ERR_INVALID_ARG, "tile id %d (10 .. 13)", tile);
+    } else {
+      g_gemm2_force_tile = tile - 10;
+      rc = launch_gemm_f64(ctx, dd, 1, m, n, tile, split_k, false, false, layout, lower_grid != 0);
+      g_gemm2_force_tile = 0;
+    }
     fail(hipStreamSynchronize(st));
   }
   if (rc == SC_OK) {

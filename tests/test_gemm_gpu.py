@@ -1,8 +1,7 @@
 """
 GPU unit tests of the f64 MFMA GEMM launch paths (csrc/gemm_f64.hip) against NumPy: every block tile of k_gemm2, the
 three operand layouts, split-K, the lower-triangle launch grid of the band reduction's SYR2K (entries above the diagonal
-must stay untouched), the XCD pairing of launches with 2-4 row tiles, ragged sizes, K = 0, and the older
-stride-agnostic kernel.  The triangular-operand and gather launches are covered through the solvers that use them
+must stay untouched), the XCD pairing of launches with 2-4 row tiles, ragged sizes, K = 0.  The triangular-operand and gather launches are covered through the solvers that use them
 (tests/test_two_stage_gpu.py, tests/test_eigh_gpu.py).  Tolerance: K * 4 ulp of the largest partial product sum.
 """
 import ctypes as C
@@ -46,7 +45,7 @@ def gemm():
     return run
 
 
-@pytest.mark.parametrize("tile", [10, 11, 12, 13, 3])
+@pytest.mark.parametrize("tile", [10, 11, 12, 13])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_layouts_and_tiles(gemm, tile, mode):
     if mode == 1:

@@ -9,7 +9,6 @@ run SPRINGCRAFT_BULGE_PERSISTENT=2
 run SPRINGCRAFT_GEMM_NO_LOWER_GRID=1 SPRINGCRAFT_GEMM_NO_BALANCE=1 SPRINGCRAFT_GEMM_NO_PAIR=1
 run SPRINGCRAFT_GEMM2_TILE=3
 run SPRINGCRAFT_GEMM2_TILE=1
-run SPRINGCRAFT_GEMM_OLD=1
 run SPRINGCRAFT_BT2_NW=4
 run SPRINGCRAFT_NO_AUX=1
 run SPRINGCRAFT_QR_UNBLOCKED=1
