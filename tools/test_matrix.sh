@@ -12,3 +12,5 @@ run SPRINGCRAFT_GEMM2_TILE=1
 run SPRINGCRAFT_BT2_NW=4
 run SPRINGCRAFT_NO_AUX=1
 run SPRINGCRAFT_QR_UNBLOCKED=1
+run SPRINGCRAFT_SYMM_SPLIT=4 SPRINGCRAFT_BT2_WAVE=1
+run SPRINGCRAFT_BT2_WAVE=0
