@@ -167,3 +167,41 @@ def test_solve_ragged_single_process():
     with pytest.raises(ValueError):
         solve_ragged([np.zeros((4, 2))], None, solver_factory=factory)
     assert solve_ragged([], None, solver_factory=factory) == []
+
+
+def test_size_buckets_properties():
+    """Buckets of similar sizes for the padded batches: a partition, deterministic, no member pays more than the ratio."""
+    from springcraft_amd.batch import size_buckets
+
+    rs = np.random.RandomState(0)
+    sizes = [int(x) for x in rs.randint(50, 2000, 200)]
+    for ratio in (1.0, 1.25, 2.0):
+        buckets = size_buckets(sizes, ratio)
+        flat = sorted(i for b in buckets for i in b)
+        assert flat == list(range(len(sizes)))                       # every structure exactly once
+        assert buckets == size_buckets(sizes, ratio)                 # deterministic
+        for b in buckets:
+            assert b == sorted(b)
+            n_max = max(sizes[i] for i in b)
+            assert all((n_max / sizes[i]) ** 3 <= ratio + 1e-12 for i in b)
+    assert all(len({sizes[i] for i in b}) == 1 for b in size_buckets(sizes, 1.0))    # ratio 1: one bucket per size
+    assert size_buckets([], 1.25) == [] and size_buckets([7], 1.25) == [[0]]
+
+
+def test_bench_numa_binding_is_best_effort():
+    """bench.py pins a rank to its GPU's NUMA node from sysfs; on a box without GPUs it must say so and change nothing."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = os.sched_getaffinity(0)
+    msg = bench.bind_rank_to_numa_node(0)
+    assert isinstance(msg, str) and msg
+    if msg.startswith("unbound"):
+        assert os.sched_getaffinity(0) == before
+    else:
+        assert os.sched_getaffinity(0) <= before
+        os.sched_setaffinity(0, before)
+    assert bench.bind_rank_to_numa_node(10 ** 6).startswith("unbound")
