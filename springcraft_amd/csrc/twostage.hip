@@ -1350,6 +1350,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   d4 zz[12];
   int fin_row = 0;
   bool have_fin = false;
+  // 8 waves = two per SIMD (w and w + 4): waves 4 .. 7 run one half-diamond behind waves 0 .. 3
+  constexpr bool kPhased = NW == 8;
+  const int lag = (kPhased && wu >= 4) ? 1 : 0;
+  constexpr int kFin0 = NW == 8 ? 10 : 16;
   BT2_STAMP_DECL
   int S_cur = 0;   // (read by the -DBT2_TRACE build only)
   (void)S_cur;
@@ -1364,9 +1368,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     for (int H = 0; H < 2; ++H) {
       const int q = 2 * k + H;                               // half index inside the group
       const double* ldsH = lds + slot * kHalfDoubles + lane;
-      const int slot_pre = slot == 0 ? 2 : slot - 1;         // ring slot of half q + 2 (= the one half q - 1 has left)
+      // the half fetched during this time slot is the one the leading wave group runs NEXT (slot index = q + lag):
+      // ring position (q + lag + 1) mod 3, the one the trailing group left at the last barrier
+      int slot_pre = slot + 1 + lag;
+      slot_pre = slot_pre >= 3 ? slot_pre - 3 : slot_pre;
       // (past the end of the group the last half is fetched again, into a slot nobody reads: no branch in the loop)
-      const double* src_pre = fgrp + (size_t)(q + 2 < nh ? q + 2 : nh - 1) * kHalfDoubles;
+      const double* src_pre = fgrp + (size_t)(q + lag + 1 < nh ? q + lag + 1 : nh - 1) * kHalfDoubles;
       BT2_STAMP(7 * H)
       if (!(dbg & 8)) barrier();   // half q complete in LDS (every wave waited for its own part); half q - 1 finished
       BT2_STAMP(7 * H + 1)
@@ -1391,36 +1398,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
       for (int f = 0; f < ((dbg & 4) ? 8 : kHalfFrags); ++f) {
         // ---- this step's piece
-        if (f < kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f);
+        // Two waves share a SIMD (w and w + 4) and the trailing one runs one half behind (lag): the pieces are placed
+        // so that the partner of a wave in a piece-heavy stretch is in a stretch of (nearly) bare MFMAs and can keep
+        // the matrix pipe fed -- the heavy pieces (DMA issue, the stores of the finished rows) sit in the first 40
+        // steps of the FIRST half, which run beside the partner's second half, whose first 40 steps carry three light
+        // pieces; the second 40 steps of both halves carry a few light ones each.
+        if (H == 0) {
+          if (f < kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f);
+        } else {
+          if (f >= 46 && f < 46 + kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f - 46);
+        }
         if (!(dbg & 2)) {
           if (H == 0) {
             // rows entering at the slide, tiles 0 and 1: requested right after the half's DMA instructions (the compiler
             // does not see those: its vmcnt for the first use of a row then covers them, being older, and nothing younger)
             if (f == kDmaPer + 1) load_raw(zn[0], win + 128);
             if (f == kDmaPer + 3) load_raw(zn[1], win + 128 + 16);
-            // rows finished at the last slide: tile i through the transposition tile at step 14 + 14 i, column halves a / b
-            // stored at steps 20 + 14 i and 22 + 14 i (the last store is 14 MFMAs before the vmcnt(0) of the half)
+            // rows finished at the last slide: tile i through the transposition tile at step 10 + 8 i (8 waves; 14 + 8 i
+            // with the 10 DMA steps of the 4-wave variant), column halves a / b stored 4 and 6 steps later
             if (have_fin) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                if (f == 14 + 14 * i) tile_to_rows(ZT(8 + i), fin_rows);
-                if (f == 20 + 14 * i) store_rows_a(fin_rows, fin_row + 16 * i);
-                if (f == 22 + 14 * i) store_rows_b(fin_rows, fin_row + 16 * i);
+                if (f == kFin0 + 8 * i) tile_to_rows(ZT(8 + i), fin_rows);
+                if (f == kFin0 + 4 + 8 * i) store_rows_a(fin_rows, fin_row + 16 * i);
+                if (f == kFin0 + 6 + 8 * i) store_rows_b(fin_rows, fin_row + 16 * i);
               }
             }
+            // tiles 0, 1 of the new rows into the spare array (free since step kFin0 + 24), then the requests for
+            // tiles 2, 3 into the same two raw registers: the youngest four loads of the half, the only ones its closing
+            // vmcnt(4) leaves in flight
+            if (f == 52) scatter_in(zn[0], sc, win + 128);
+            if (f == 58) scatter_out(ZT(8), sc, win + 128);
+            if (f == 60) scatter_in(zn[1], sc, win + 128 + 16);
+            if (f == 66) scatter_out(ZT(9), sc, win + 128 + 16);
+            if (f == 68) load_raw(zn[0], win + 128 + 32);
+            if (f == 70) load_raw(zn[1], win + 128 + 48);
           } else {
-            // new rows: tiles 0, 1 (requested in the first half) go through the transposition tile at steps 8 / 16 and
-            // into the spare array six steps later; tiles 2, 3 are requested at steps 24 / 26, scattered at 60 / 68
-            if (f == 8) scatter_in(zn[0], sc, win + 128);
-            if (f == 14) scatter_out(ZT(8), sc, win + 128);
-            if (f == 16) scatter_in(zn[1], sc, win + 128 + 16);
-            if (f == 22) scatter_out(ZT(9), sc, win + 128 + 16);
-            if (f == 24) load_raw(zn[0], win + 128 + 32);
-            if (f == 26) load_raw(zn[1], win + 128 + 48);
-            if (f == 60) scatter_in(zn[0], sc, win + 128 + 32);
-            if (f == 66) scatter_out(ZT(10), sc, win + 128 + 32);
-            if (f == 68) scatter_in(zn[1], sc, win + 128 + 48);
-            if (f == 74) scatter_out(ZT(11), sc, win + 128 + 48);
+            // tiles 2, 3 (requested ~40 steps ago) before this half's DMA instructions are issued: the compiler's
+            // vmcnt(0) for them must not cover the DMA
+            if (f == 28) scatter_in(zn[0], sc, win + 128 + 32);
+            if (f == 34) scatter_out(ZT(10), sc, win + 128 + 32);
+            if (f == 36) scatter_in(zn[1], sc, win + 128 + 48);
+            if (f == 42) scatter_out(ZT(11), sc, win + 128 + 48);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1450,7 +1469,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       }
       BT2_TRACE_POINT(H, 80)
       BT2_STAMP(7 * H + 6)
-      wait_vm0();                  // this wave's part of half q + 1 (issued one half ago) and of half q + 2, the stores
+      // this wave's part of the half fetched during this slot must have landed before the barrier that opens the next
+      // slot (and the stores of the finished rows with it); after a first half the four youngest loads (new rows, tiles
+      // 2 and 3) stay in flight
+      if (H == 0 && !(dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else wait_vm0();
       slot = slot == 2 ? 0 : slot + 1;
     }
     // ---- slide by 64 rows = the next phase.  After the last diamond of a group the whole window goes back to memory.
@@ -1486,10 +1509,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     barrier();                       // every wave has left the previous group: the whole ring is free
     if (!(dbg & 1)) {
       for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp, 0, j);
-      for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp + kHalfDoubles, 1, j);
     }
     wait_vm0();
     __builtin_amdgcn_sched_barrier(0);
+    if (lag) {
+      // time slot 0 of the trailing wave group: the leading group runs half 0; only this group's share of half 1's DMA
+      if (!(dbg & 8)) barrier();
+      if (!(dbg & 1)) {
+        for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp + (size_t)(1 < nh ? 1 : 0) * kHalfDoubles, 1, j);
+      }
+      wait_vm0();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     int slot = 0;                    // ring slot of the half about to run
     int ph = 0;
     for (int k = 0; k < nk; ++k, win += 64) {
@@ -1499,6 +1530,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       else diamond(std::integral_constant<int, 2>{}, fgrp, k, nh, more, slot, win);
       ph = ph == 2 ? 0 : ph + 1;
     }
+    // time slot nh of the leading group (the trailing one runs its last half): one barrier, so that both count the same
+    if (kPhased && !lag && !(dbg & 8)) barrier();
   }
   BT2_STAMP_WRITE
 }
