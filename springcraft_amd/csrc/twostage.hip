@@ -1025,6 +1025,9 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
 //     products consume them, 160 per diamond = 80 KB;
 //   * a workgroup streams the fragments into a ring of three half-diamond buffers (40 KB each) with LDS-DMA
 //     (global_load_lds_dwordx4, no staging registers), two halves ahead of the MFMAs; one barrier per half.
+#ifndef BT2_PRIO
+#define BT2_PRIO 0
+#endif
 #ifndef BT2_DBG
 #define BT2_DBG 0
 #endif
@@ -1214,8 +1217,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   const int gc = lane >> 3, gr = (lane & 7) * 2;
   const int col_a = chunk * kCols + 16 * w + gc, col_b = col_a + 8;
   double* z_mat = z_all + (size_t)mat * stride_z;
-  zptr za = (zptr)(z_mat + (size_t)(col_a < ncols ? col_a : ncols - 1) * n + gr);
-  zptr zb = (zptr)(z_mat + (size_t)(col_b < ncols ? col_b : ncols - 1) * n + gr);
+  // addresses = one wave-uniform base (scalar registers; the row of an access is added there) + a 32-bit element
+  // offset per lane: no 64-bit vector arithmetic per access
+  const int base_col = std::max(0, std::min(chunk * kCols + 16 * w, ncols - 16));
+  const gdptr zw = wave_uniform(z_mat + (size_t)base_col * n);
+  // (BYTE offsets: a 32-bit offset the compiler has to scale by 8 may exceed 32 bits for all it knows, and it falls back
+  // to 64-bit vector adds)
+  typedef char __attribute__((address_space(1)))* gbptr;
+  // the base of row `row` as an opaque scalar value (otherwise the compiler re-associates base + row + lane offset into
+  // a hoisted 64-bit per-lane pointer + row, one 64-bit vector add per access again)
+  // (and the lane offset re-materialised in the block of the access: hoisted out of the loop it arrives there as a 64-bit
+  // value the instruction selector cannot see the zero extension of, and the scalar-base form is not chosen)
+  auto lane_off = [&](unsigned e) -> unsigned {
+    asm volatile("" : "+v"(e));
+    return e;
+  };
+  auto row_base = [&](int row) -> gbptr {
+    unsigned long long b = (unsigned long long)(size_t)(zw + row);
+    asm volatile("" : "+s"(b));
+    return (gbptr)(size_t)b;
+  };
+  const unsigned ea = 8u * (unsigned)(((col_a < ncols ? col_a : ncols - 1) - base_col) * n + gr);
+  const unsigned eb = 8u * (unsigned)(((col_b < ncols ? col_b : ncols - 1) - base_col) * n + gr);
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
   typedef const d2u __attribute__((address_space(1)))* z2ptr_c;
   typedef d2u __attribute__((address_space(1)))* z2ptr;
@@ -1225,8 +1248,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   // instead and shifted back when it is scattered.
   auto load_raw = [&](Raw& t, int row0) {
     const int rs = row0 < n - 16 ? row0 : n - 16;
-    t.a = *(z2ptr_c)(za + rs);
-    t.b = *(z2ptr_c)(zb + rs);
+    const gbptr zr = row_base(rs);
+    t.a = *(z2ptr_c)(zr + lane_off(ea));
+    t.b = *(z2ptr_c)(zr + lane_off(eb));
   };
   // raw tile -> accumulator layout, rows beyond the matrix and columns beyond ncols masked to zero
   auto scatter_tile = [&](d4& t, const Raw& raw, int row0) {
@@ -1254,17 +1278,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     asm volatile("" ::: "memory");
   };
   auto store_rows = [&](const Raw& v, int row0) {
+    const gbptr zr = row_base(row0);
     if (row0 + 16 <= n) {
-      if (col_a < ncols) *(z2ptr)(za + row0) = v.a;
-      if (col_b < ncols) *(z2ptr)(zb + row0) = v.b;
+      if (col_a < ncols) *(z2ptr)(zr + lane_off(ea)) = v.a;
+      if (col_b < ncols) *(z2ptr)(zr + lane_off(eb)) = v.b;
     } else {
       if (col_a < ncols) {
-        if (row0 + gr < n) za[row0] = v.a[0];
-        if (row0 + gr + 1 < n) za[row0 + 1] = v.a[1];
+        if (row0 + gr < n) *(gdptr)(zr + ea) = v.a[0];
+        if (row0 + gr + 1 < n) *(gdptr)(zr + ea + 8) = v.a[1];
       }
       if (col_b < ncols) {
-        if (row0 + gr < n) zb[row0] = v.b[0];
-        if (row0 + gr + 1 < n) zb[row0 + 1] = v.b[1];
+        if (row0 + gr < n) *(gdptr)(zr + eb) = v.b[0];
+        if (row0 + gr + 1 < n) *(gdptr)(zr + eb + 8) = v.b[1];
       }
     }
   };
@@ -1275,14 +1300,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   };
   // the same in pieces of a few instructions (one piece per MFMA in the diamond loop): one column half per piece, the
   // tile that sticks out of the matrix handled by lane predicates instead of a second code path
-  auto store_half = [&](zptr zc, bool col_in, const d2u& v, int row0) {
+  auto store_half = [&](unsigned ec, bool col_in, const d2u& v, int row0) {
+    const gbptr zr = row_base(row0);
     if (col_in) {
-      if (row0 + gr + 1 < n) *(z2ptr)(zc + row0) = v;
-      else if (row0 + gr < n) zc[row0] = v[0];
+      if (row0 + gr + 1 < n) *(z2ptr)(zr + lane_off(ec)) = v;
+      else if (row0 + gr < n) *(gdptr)(zr + lane_off(ec)) = v[0];
     }
   };
-  auto store_rows_a = [&](const Raw& v, int row0) { store_half(za, col_a < ncols, v.a, row0); };
-  auto store_rows_b = [&](const Raw& v, int row0) { store_half(zb, col_b < ncols, v.b, row0); };
+  auto store_rows_a = [&](const Raw& v, int row0) { store_half(ea, col_a < ncols, v.a, row0); };
+  auto store_rows_b = [&](const Raw& v, int row0) { store_half(eb, col_b < ncols, v.b, row0); };
   // scatter_tile in two pieces: raw tile -> transposition tile -> four values per lane (scatter_in); masks and the move
   // into the accumulator layout a few MFMAs later, when the LDS reads have come back (scatter_out)
   auto scatter_in = [&](const Raw& raw, double (&tmp)[4], int row0) {
@@ -1308,31 +1334,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     }
     t = d4{x[0], x[1], x[2], x[3]};
   };
-  // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a half-diamond; the waves share the instructions.
+  // LDS-DMA: instruction q moves bytes [1024 q, 1024 q + 1024) of a half-diamond; wave w issues q = kDmaPer w + j.
   // Issued from inline asm: hipcc then keeps no scoreboard entry for them (with the builtin it guards later LDS reads
   // and register reuse with vmcnt(0), i.e. waits for the DMA it has just issued); their completion is counted by hand:
-  // every wait for them below is an explicit vmcnt(0).  M0 (the LDS destination base) is saved and restored.
+  // every wait for them below is an explicit vmcnt.
+  // M0 (the LDS destination base) is written ONCE per five instructions: a write to M0 waits until the LDS-DMA
+  // instructions in flight have landed (measured: with M0 saved / set / restored around every instruction the five
+  // issued one memory latency apart, ~2600 cycles per half in which the wave issued nothing else).  The instruction's
+  // immediate offset moves both the global and the LDS address, so five consecutive kilobytes share one M0 and one
+  // scalar base, both pointing at the middle one.  Nothing else in this kernel uses M0 (saved / restored around the
+  // whole loop).
   const unsigned lds_base = (unsigned)(size_t)(lvoid)lds;
   constexpr int kDmaInstr = kHalfDoubles * 8 / 1024;          // 40 per half
-  constexpr int kDmaPer = (kDmaInstr + NW - 1) / NW;          // per wave: 5 (8 waves) or 10 (4 waves)
-  // this wave's j-th instruction of the half at `src` into ring slot `slot`.  Address = scalar base (uniform: the half's
-  // address + 1024 q) + one 32-bit lane offset, so that no per-instruction vector address stays live across the loop
+  constexpr int kDmaPer = kDmaInstr / NW;                     // per wave: 5 (8 waves) or 10 (4 waves)
+  static_assert(kDmaPer * NW == kDmaInstr && kDmaPer % 5 == 0, "DMA instructions are shared in fives");
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const unsigned voff = (unsigned)lane * 16u;
-  auto dma_one = [&](const double* src, int slot, int j) {
-    const int q = wu + NW * j;
-    if (q < kDmaInstr) {
-      unsigned keep;
-      const unsigned long long ga = (unsigned long long)(size_t)src + (unsigned long long)q * 1024ull;
-      // (the builtin returns int: widen through unsigned, or a low half with bit 31 set would smear into the high half)
-      const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
-      const unsigned ga_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
-      const unsigned long long sbase = ((unsigned long long)ga_hi << 32) | (unsigned long long)ga_lo;
-      const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * kHalfDoubles) * 8u + (unsigned)q * 1024u);
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(voff), "s"(sbase), "s"(lq)
-                   : "memory");
+  // M0 and the scalar base for instructions 5 g .. 5 g + 4 of this wave, half at `src`, ring slot `slot`
+  auto dma_begin = [&](const double* src, int slot, int g) -> unsigned long long {
+    const int qc = wu * kDmaPer + 5 * g + 2;
+    const unsigned long long ga = (unsigned long long)(size_t)src + (unsigned long long)qc * 1024ull;
+    // (the builtin returns int: widen through unsigned, or a low half with bit 31 set would smear into the high half)
+    const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
+    const unsigned ga_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
+    const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * kHalfDoubles) * 8u + (unsigned)qc * 1024u);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lq) : "memory");
+    return ((unsigned long long)ga_hi << 32) | (unsigned long long)ga_lo;
+  };
+  auto dma_go = [&](unsigned long long sbase, int i) {   // i = 0 .. 4 (a constant after unrolling)
+    switch (i) {
+      case 0: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-2048" : : "v"(voff), "s"(sbase) : "memory"); break;
+      case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-1024" : : "v"(voff), "s"(sbase) : "memory"); break;
+      case 2: asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase) : "memory"); break;
+      case 3: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voff), "s"(sbase) : "memory"); break;
+      default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voff), "s"(sbase) : "memory"); break;
+    }
+  };
+  auto dma_half = [&](const double* src, int slot) {     // all of this wave's instructions at once (group prologue)
+    unsigned long long sbase = 0;
+#pragma unroll
+    for (int j = 0; j < kDmaPer; ++j) {
+      if (j % 5 == 0) sbase = dma_begin(src, slot, j / 5);
+      dma_go(sbase, j % 5);
     }
   };
   auto wait_vm0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -1351,8 +1394,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   int fin_row = 0;
   bool have_fin = false;
   // 8 waves = two per SIMD (w and w + 4): waves 4 .. 7 run one half-diamond behind waves 0 .. 3
-  constexpr bool kPhased = NW == 8;
-  const int lag = (kPhased && wu >= 4) ? 1 : 0;
+#ifndef BT2_LAGSEL
+#define BT2_LAGSEL 0   // experiments: 1 = odd waves trail instead of waves 4 .. 7, 2 = nobody trails
+#endif
+  constexpr bool kPhased = NW == 8 && BT2_LAGSEL != 2;
+  const int lag = (kPhased && (BT2_LAGSEL == 1 ? (wu & 1) != 0 : wu >= 4)) ? 1 : 0;
   constexpr int kFin0 = NW == 8 ? 10 : 16;
   BT2_STAMP_DECL
   int S_cur = 0;   // (read by the -DBT2_TRACE build only)
@@ -1393,20 +1439,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       constexpr int kAhead = 8;                               // fragments in flight between LDS and the MFMA that uses them
       double fq[kAhead];
       double sc[4];                                           // a new tile between the transposition tile and its select
+      unsigned long long dma_base = 0;                        // scalar base of the DMA instructions being issued
 #pragma unroll
       for (int j = 0; j < kAhead; ++j) fq[j] = ldsH[j * 64];
 #pragma unroll
       for (int f = 0; f < ((dbg & 4) ? 8 : kHalfFrags); ++f) {
         // ---- this step's piece
+#if BT2_PRIO == 1
+        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(2);
+        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(0);
+#elif BT2_PRIO == 2
+        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(2);
+        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(0);
+        if (H == 1 && f == 26) __builtin_amdgcn_s_setprio(1);
+        if (H == 1 && f == 52) __builtin_amdgcn_s_setprio(0);
+#elif BT2_PRIO == 3
+        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(0);
+        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(2);
+#elif BT2_PRIO == 4
+        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(3);
+        if (H == 0 && f == 72) __builtin_amdgcn_s_setprio(0);
+#endif
         // Two waves share a SIMD (w and w + 4) and the trailing one runs one half behind (lag): the pieces are placed
         // so that the partner of a wave in a piece-heavy stretch is in a stretch of (nearly) bare MFMAs and can keep
         // the matrix pipe fed -- the heavy pieces (DMA issue, the stores of the finished rows) sit in the first 40
         // steps of the FIRST half, which run beside the partner's second half, whose first 40 steps carry three light
         // pieces; the second 40 steps of both halves carry a few light ones each.
         if (H == 0) {
-          if (f < kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f);
+          if (f < kDmaPer && !(dbg & 1)) {
+            if (f % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, f / 5);
+            dma_go(dma_base, f % 5);
+          }
         } else {
-          if (f >= 46 && f < 46 + kDmaPer && !(dbg & 1)) dma_one(src_pre, slot_pre, f - 46);
+          if (f >= 46 && f < 46 + kDmaPer && !(dbg & 1)) {
+            if ((f - 46) % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, (f - 46) / 5);
+            dma_go(dma_base, (f - 46) % 5);
+          }
         }
         if (!(dbg & 2)) {
           if (H == 0) {
@@ -1444,7 +1512,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef BT2_STAMPS
+#ifdef BT2_STAMPS_FINE   // the first half's four inner stamps after steps 2, 5, 8, 11 (or 13, 16, 19, 22 with =2) instead
+        if (H == 0 && f >= 3 + 11 * (BT2_STAMPS_FINE - 1) && f <= 12 + 11 * (BT2_STAMPS_FINE - 1) &&
+            (f - 11 * (BT2_STAMPS_FINE - 1)) % 3 == 0) BT2_STAMP(1 + (f - 11 * (BT2_STAMPS_FINE - 1)) / 3)
+        if (H == 1 && (f == 16 || f == 32 || f == 48 || f == 64)) BT2_STAMP(7 * H + 1 + f / 16)
+#else
         if (f == 16 || f == 32 || f == 48 || f == 64) BT2_STAMP(7 * H + 1 + f / 16)
+#endif
 #endif
         BT2_TRACE_POINT(H, f)
         // ---- the MFMA
@@ -1493,6 +1567,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     __builtin_amdgcn_sched_barrier(0);
 #undef ZT
   };
+  unsigned m0_keep;
+  asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
   for (int S = SL.ngroups - 1; S >= 0; --S) {
     S_cur = S;
     const int d0 = dia_off[S], nk = dia_off[S + 1] - d0;
@@ -1508,7 +1584,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     }
     barrier();                       // every wave has left the previous group: the whole ring is free
     if (!(dbg & 1)) {
-      for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp, 0, j);
+      dma_half(fgrp, 0);
     }
     wait_vm0();
     __builtin_amdgcn_sched_barrier(0);
@@ -1516,7 +1592,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       // time slot 0 of the trailing wave group: the leading group runs half 0; only this group's share of half 1's DMA
       if (!(dbg & 8)) barrier();
       if (!(dbg & 1)) {
-        for (int j = 0; j < kDmaPer; ++j) dma_one(fgrp + (size_t)(1 < nh ? 1 : 0) * kHalfDoubles, 1, j);
+        dma_half(fgrp + (size_t)(1 < nh ? 1 : 0) * kHalfDoubles, 1);
       }
       wait_vm0();
       __builtin_amdgcn_sched_barrier(0);
@@ -1533,6 +1609,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     // time slot nh of the leading group (the trailing one runs its last half): one barrier, so that both count the same
     if (kPhased && !lag && !(dbg & 8)) barrier();
   }
+  asm volatile("s_mov_b32 m0, %0" : : "s"(m0_keep));
   BT2_STAMP_WRITE
 }
 
