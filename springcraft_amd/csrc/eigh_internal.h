@@ -106,7 +106,7 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
 struct SbLayout {
   int n;
   long long slab;
-  long long vw, wv;   // [V|W], [W|V] panels, n x 128
+  long long vw, wv;   // [V|W], [W|V] panels of TWO consecutive panels, n x 256 (the trailing update takes them together)
   long long xv;       // [X1|X2|V], n x 192
   long long qrpart, qrpiv;   // panel-QR partial Gram rows / pivot row (two copies each)
   long long qrpart8;         // blocked panel QR: per-chunk partial products of an inner block, nchunk x 8 x 64
@@ -114,6 +114,8 @@ struct SbLayout {
   int symm_split;     // 1: no split
   long long small;    // split-K slices of V^T [X1|X2|V]
   long long cmat;     // [T; T; -S/2], 192 x 64
+  long long small2;   // split-K slices of [W1|V1]^T V2 (second panel of a pair), 128 x 64 each
+  long long p2;       // their sum
   long long ab;       // band storage 128 x n
   int ngroups;        // sweep groups (64 sweeps each)
   long long ndia;     // diamonds

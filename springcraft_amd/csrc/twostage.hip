@@ -32,6 +32,7 @@ constexpr int kDiaLd = 128;       // leading dimension of a diamond (kB + kG - 1
 constexpr int kDiaSize = kDiaLd * kG;
 constexpr int kQrRows = 128;      // rows of the panel one k_panel_qr workgroup owns
 constexpr int kSmallSplit = 8;    // split-K of the V^T [X1|X2|V] product
+constexpr int kDescKinds = 9;     // GEMM records per panel and matrix (stage 1)
 
 struct HH {
   double beta, tau, scale;
@@ -479,6 +480,16 @@ __global__ __launch_bounds__(256) void k_sum_xslices(double* __restrict__ sb_all
   double s = 0.0;
   for (int q = 0; q < p; ++q) s += src[(size_t)q * n * kB];
   sb[SL.xv + (size_t)(which * kB + c) * n + r] = s;
+}
+
+// second panel of a pair: P2 = [W1|V1]^T V2 (128 x 64) from its split-K slices
+__global__ __launch_bounds__(256) void k_sum_p2(double* __restrict__ sb_all, SbLayout SL) {
+  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
+  const int i = blockIdx.x * 256 + threadIdx.x;   // 0 .. 2 kB kB - 1
+  double acc = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < kSmallSplit; ++sl) acc += sb[SL.small2 + (size_t)sl * 2 * kB * kB + i];
+  sb[SL.p2 + i] = acc;
 }
 
 // One workgroup per matrix: T (larft, forward columnwise) from tau and G = V^T V;  S = T^T (V^T X) T;
@@ -1730,8 +1741,8 @@ size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
   long long off = 0;
   auto take = [&](long long cnt) { long long o = off; off += (cnt + 31) / 32 * 32; return o; };
   const int nchunk = (n + kQrRows - 1) / kQrRows + 1;
-  L.vw = take((long long)n * 2 * kB);
-  L.wv = take((long long)n * 2 * kB);
+  L.vw = take((long long)n * 4 * kB);
+  L.wv = take((long long)n * 4 * kB);
   L.xv = take((long long)n * 3 * kB);
   L.symm_split = symm_split_for(n, batch);
   L.xsplit = L.symm_split > 1 ? take((long long)2 * L.symm_split * n * kB) : 0;
@@ -1740,6 +1751,8 @@ size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
   L.qrpart8 = take((long long)nchunk * 8 * kB);
   L.small = take((long long)kSmallSplit * kB * 3 * kB);
   L.cmat = take(3 * kB * kB);
+  L.small2 = take((long long)kSmallSplit * 2 * kB * kB);
+  L.p2 = take(2 * kB * kB);
   L.ab = take((long long)kLdab * n);
   // diamonds
   const int nsweep = std::max(n - 2, 0);
@@ -1760,7 +1773,7 @@ size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
 
 int sb_desc_count(int n, int batch) {
   const int npanels = n / kB + 1;
-  return npanels * 6 * batch;
+  return npanels * kDescKinds * batch;
 }
 
 
@@ -1787,17 +1800,32 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_HIP(ctx, hipEventRecord(ev[0], st));
   }
 
-  // ---- descriptors of stage 1: per panel [symm x 2 | vtx | w x 2 | syr2k] x batch
+  // ---- descriptors of stage 1: per panel kDescKinds kinds x batch
+  // Panels are taken in PAIRS where the trailing matrix is large enough: the second panel of a pair is factored from
+  // columns that received the first panel's update alone (record D), its X = A22 V2 is computed from the NOT yet updated
+  // trailing matrix and corrected by - [V1|W1] ([W1|V1]^T V2) (records Q, Corr), and one trailing update
+  // A22 -= [V1|W1|V2|W2] [W1|V1|W2|V2]^T (K = 256) serves both panels: the lower triangle is read and written once per
+  // 128 columns of band instead of once per 64 (at K = 128 the C traffic of a tile takes as long as its MFMAs).
   int npanels = 0;
   while (n - (npanels + 1) * kB >= 2) ++npanels;
-  std::vector<GemmDesc> h((size_t)npanels * 6 * batch);
+  static const bool pair_env = [] { const char* e = getenv("SPRINGCRAFT_PANEL_PAIRS"); return !e || atoi(e) != 0; }();
+  std::vector<int> role((size_t)npanels, 0);   // 0 single, 1 first of a pair, 2 second of a pair
+  if (pair_env)
+    for (int p = 0; p + 1 < npanels;) {
+      const int m2 = n - (p + 2) * kB;
+      if (m2 >= 4 * kB) { role[(size_t)p] = 1; role[(size_t)p + 1] = 2; p += 2; }
+      else ++p;
+    }
+  std::vector<GemmDesc> h((size_t)npanels * kDescKinds * batch);
   for (int p = 0; p < npanels; ++p) {
     const int j0 = p * kB, r0 = j0 + kB, m = n - r0;
+    const int rl = role[(size_t)p];
+    const long long vw_w = rl == 2 ? 3 * kB : kB, wv_w = rl == 2 ? 2 * kB : 0;   // columns W goes to
     for (int b = 0; b < batch; ++b) {
       double* A = d_a + (size_t)b * stride_a;
       double* sb = d_sb_ws + (size_t)b * SL.slab;
       double* a22 = A + (size_t)r0 * n + r0;
-      GemmDesc* g = &h[((size_t)p * batch + b) * 6];
+      GemmDesc* g = &h[((size_t)p * batch + b) * kDescKinds];
       // X1 = L V
       GemmDesc X1{};
       X1.a = a22; X1.sa_i = 1; X1.sa_k = n; X1.a_tri = 1;
@@ -1823,37 +1851,50 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       P.m = kB; P.n = 3 * kB; P.k = m; P.alpha = 1.0; P.beta = 0.0;
       P.split_stride = (long long)kB * 3 * kB;
       g[2] = P;
-      // W = [X1 | X2 | V] C  -> [V|W] second half and [W|V] first half
+      // W = [X1 | X2 | V] C  -> its column block of [V|W..] and of [W|V..]
       GemmDesc W{};
       W.a = sb + SL.xv + r0; W.sa_i = 1; W.sa_k = n;
       W.b = sb + SL.cmat; W.sb_k = 1; W.sb_j = 3 * kB;
-      W.c = sb + SL.vw + (size_t)kB * n + r0; W.ldc = n;
+      W.c = sb + SL.vw + (size_t)vw_w * n + r0; W.ldc = n;
       W.m = m; W.n = kB; W.k = 3 * kB; W.alpha = 1.0; W.beta = 0.0;
       g[3] = W;
-      W.c = sb + SL.wv + r0;
+      W.c = sb + SL.wv + (size_t)wv_w * n + r0;
       g[4] = W;
-      // A22 -= [V|W] [W|V]^T, lower triangle
+      // trailing update, lower triangle: A22 -= [V|W] [W|V]^T (single panel) or the four-block form (second of a pair)
       GemmDesc R{};
       R.a = sb + SL.vw + r0; R.sa_i = 1; R.sa_k = n;
       R.b = sb + SL.wv + r0; R.sb_k = n; R.sb_j = 1;
       R.c = a22; R.ldc = n;
-      R.m = m; R.n = m; R.k = 2 * kB; R.alpha = -1.0; R.beta = 1.0;
+      R.m = m; R.n = m; R.k = rl == 2 ? 4 * kB : 2 * kB; R.alpha = -1.0; R.beta = 1.0;
       R.lower_only = 1;
       g[5] = R;
+      // first of a pair: only the next panel's 64 columns (and the band block above them) get this panel's update now
+      GemmDesc D = R;
+      D.n = kB; D.k = 2 * kB;
+      g[6] = D;
+      // second of a pair (rows r0 .. of the first panel's blocks): P2 = [W1|V1]^T V2, X1 -= [V1|W1] P2
+      GemmDesc Q{};
+      Q.a = sb + SL.wv + r0; Q.sa_i = n; Q.sa_k = 1;
+      Q.b = sb + SL.xv + (size_t)2 * kB * n + r0; Q.sb_k = 1; Q.sb_j = n;
+      Q.c = sb + SL.small2; Q.ldc = 2 * kB;
+      Q.m = 2 * kB; Q.n = kB; Q.k = m; Q.alpha = 1.0; Q.beta = 0.0;
+      Q.split_stride = (long long)2 * kB * kB;
+      g[7] = Q;
+      GemmDesc Cr{};
+      Cr.a = sb + SL.vw + r0; Cr.sa_i = 1; Cr.sa_k = n;
+      Cr.b = sb + SL.p2; Cr.sb_k = 1; Cr.sb_j = 2 * kB;
+      Cr.c = sb + SL.xv + r0; Cr.ldc = n;
+      Cr.m = m; Cr.n = kB; Cr.k = 2 * kB; Cr.alpha = -1.0; Cr.beta = 1.0;
+      g[8] = Cr;
     }
   }
   // regroup so that each launch's records are contiguous: [panel][kind][batch]
   std::vector<GemmDesc> hs(h.size());
   for (int p = 0; p < npanels; ++p)
     for (int b = 0; b < batch; ++b) {
-      const GemmDesc* g = &h[((size_t)p * batch + b) * 6];
-      GemmDesc* o = &hs[(size_t)p * 6 * batch];
-      o[0 * batch + b] = g[0];              // symm: 2 * batch records: [X1 x batch | X2 x batch]
-      o[1 * batch + b] = g[1];
-      o[2 * batch + b] = g[2];
-      o[3 * batch + b] = g[3];              // w: 2 * batch records
-      o[4 * batch + b] = g[4];
-      o[5 * batch + b] = g[5];
+      const GemmDesc* g = &h[((size_t)p * batch + b) * kDescKinds];
+      GemmDesc* o = &hs[(size_t)p * kDescKinds * batch];
+      for (int kd = 0; kd < kDescKinds; ++kd) o[(size_t)kd * batch + b] = g[kd];
     }
   if (!hs.empty()) SC_TRY(sc_stage_upload(ctx, d_descs, hs.data(), hs.size() * sizeof(GemmDesc)));
   const std::vector<int> doff = dia_offsets(n);
@@ -1870,7 +1911,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
   static const bool blocked_qr = getenv("SPRINGCRAFT_QR_UNBLOCKED") == nullptr;
   PhaseTimer t_qr(ctx, "panel_qr", st), t_symm(ctx, "symm", st), t_syr2k(ctx, "syr2k", st), t_bulge(ctx, "bulge", st);
-  // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, SYR2K.
+  // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, the trailing update
+  // its role asks for (single: SYR2K; first of a pair: the next panel's columns only; second: the joint update).
   auto run_panel = [&](int p, int lo, int hi, hipStream_t ps, bool timed) -> int {
     struct StreamScope {   // launch_gemm_f64 launches on the context's stream
       sc_ctx* c; hipStream_t old;
@@ -1878,6 +1920,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       ~StreamScope() { c->stream = old; }
     } scope(ctx, ps);
     const int nb = hi - lo;
+    const int rl = role[(size_t)p];
     double* a_h = d_a + (size_t)lo * stride_a;
     double* tri_h = d_tri_ws + (size_t)lo * TL.slab;
     double* sb_h = d_sb_ws + (size_t)lo * SL.slab;
@@ -1885,31 +1928,38 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const int nr = std::min(kB, m - 1);
     const int nchunks = (m + kQrRows - 1) / kQrRows;
     const dim3 qgrid((unsigned)nchunks, (unsigned)nb);
+    SbLayout SQ = SL;     // where the panel QR leaves V: the second panel of a pair uses the second half of [V|W..], [W|V..]
+    if (rl == 2) { SQ.vw += (long long)2 * kB * n; SQ.wv += (long long)2 * kB * n; }
     if (timed) t_qr.start();
     if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
-      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, 0, nr, kIb);
+      hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, 0, nr, kIb);
       for (int c0 = 0; c0 < kB; c0 += kIb) {
         for (int j = c0 + 1; j < c0 + kIb; ++j)
-          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, j, nr,
+          hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, j, nr,
                              c0 + kIb);
         // (their LDS image holds columns c0 .. kB-1 only)
         const size_t cut = sizeof(double) * (size_t)c0 * (kQrRows + 1);
-        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, c0);
+        hipLaunchKernelGGL(k_pqr_blk_a, qgrid, dim3(256), lds_blk_a - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, c0);
         if (c0 + kIb < kB)
-          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, c0);
+          hipLaunchKernelGGL(k_pqr_blk_b, qgrid, dim3(256), lds_blk_b - cut, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, c0);
       }
     } else {
       for (int j = 0; j <= nr; ++j)
-        hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, ps, a_h, stride_a, tri_h, TL, sb_h, SL, j0, j, nr, kB);
+        hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, j, nr, kB);
     }
     if (timed) t_qr.stop();
-    const GemmDesc* g = d_descs + (size_t)p * 6 * batch;   // [kind][batch]
+    const GemmDesc* g = d_descs + (size_t)p * kDescKinds * batch;   // [kind][batch]
     if (timed) t_symm.start();
     SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAmBk));           // X1 = L V
     SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAkBk));   // X2 = strict(L)^T V
     if (SL.symm_split > 1)
       hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), 2 * kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
+    if (rl == 2) {   // the trailing matrix has not seen the first panel's update yet: X1 -= [V1|W1] ([W1|V1]^T V2)
+      SC_TRY(launch_gemm_f64(ctx, g + 7 * batch + lo, nb, 2 * kB, kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
+      hipLaunchKernelGGL(k_sum_p2, dim3((unsigned)(2 * kB * kB / 256), (unsigned)nb), dim3(256), 0, ps, sb_h, SL);
+      SC_TRY(launch_gemm_f64(ctx, g + 8 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
+    }
     if (timed) t_symm.stop();
     SC_TRY(launch_gemm_f64(ctx, g + 2 * batch + lo, nb, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
     hipLaunchKernelGGL(k_sb_small, dim3((unsigned)nb), dim3(256), lds_small, ps, tri_h, TL, sb_h, SL, j0);
@@ -1920,7 +1970,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       SC_TRY(launch_gemm_f64(ctx, g + 4 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
     }
     if (timed) t_syr2k.start();
-    SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
+    if (rl == 1)
+      SC_TRY(launch_gemm_f64(ctx, g + 6 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBn));
+    else
+      SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
     if (timed) t_syr2k.stop();
     return SC_OK;
   };
