@@ -1311,9 +1311,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   };
   // the same in pieces of a few instructions (one piece per MFMA in the diamond loop): one column half per piece, the
   // tile that sticks out of the matrix handled by lane predicates instead of a second code path
+  // (all 16 NW columns of the workgroup inside the matrix: with the tile inside too, the store needs no lane predicate
+  // -- one scalar branch per piece instead of a dozen exec-mask branches)
+  const bool full_cols = chunk * kCols + kCols <= ncols;
   auto store_half = [&](unsigned ec, bool col_in, const d2u& v, int row0) {
     const gbptr zr = row_base(row0);
-    if (col_in) {
+    if (full_cols && row0 + 16 <= n) {
+      *(z2ptr)(zr + lane_off(ec)) = v;
+    } else if (col_in) {
       if (row0 + gr + 1 < n) *(z2ptr)(zr + lane_off(ec)) = v;
       else if (row0 + gr < n) *(gdptr)(zr + lane_off(ec)) = v[0];
     }
