@@ -1093,6 +1093,10 @@ constexpr int kFragDoubles = kDiaFrags * 64;       // 10240 doubles = 80 KB
 __host__ __device__ constexpr int mf_p1(int st, int rt, int r) { return (3 - st) * kMiniFrags + 4 * (rt - st) + r; }
 __host__ __device__ constexpr int mf_p2(int st, int rt, int r) { return (3 - st) * kMiniFrags + 20 + 5 * r + (rt - st); }
 static_assert(mf_p2(0, 4, 3) == kDiaFrags - 1 && mf_p1(3, 3, 0) == 0, "fragment order");
+// Where lane l's value of fragment f lives inside a diamond's block: the two fragments of an even / odd pair of steps
+// side by side, so that a lane fetches both with ONE 16-byte LDS read (ds_read_b128 runs at the full LDS rate, 8-byte
+// reads at half of it -- and the fragment reads are most of the kernel's LDS traffic).
+__host__ __device__ constexpr int frag_off(int f, int l) { return ((f >> 1) * 64 + l) * 2 + (f & 1); }
 
 typedef const double __attribute__((address_space(1)))* zptr_c;   // global_load / global_store, never flat
 typedef double __attribute__((address_space(1)))* zptr;
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_dia_tfactor2(double* __restrict__ sb_al
   for (int idx = tid; idx < 4 * 20 * 64; idx += 256) {
     const int l = idx & 63, f = idx >> 6;
     const int st = f / 20, j = f % 20, rt = st + j / 4, r = j % 4;
-    frag[(size_t)mf_p1(st, rt, r) * 64 + l] = V(16 * rt + 4 * r + (l >> 4), 16 * st + (l & 15));
+    frag[frag_off(mf_p1(st, rt, r), l)] = V(16 * rt + 4 * r + (l >> 4), 16 * st + (l & 15));
   }
   // ---- fragments of -(V T): tile (st, rt) transposed,  D'[sweep i][row j] = sum_l T_st[l][i] V[16 rt + j][16 st + l]
   for (int q = w; q < 20; q += 4) {
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_dia_tfactor2(double* __restrict__ sb_al
     const d4 d = mma_range(d4{0, 0, 0, 0}, 0, 4, fr, fk, [&](int i, int k) { return Ts[st][k * 17 + i]; },
                            [&](int k, int j) { return V(16 * rt + j, 16 * st + k); });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) frag[(size_t)mf_p2(st, rt, r) * 64 + lane] = -d[r];
+    for (int r = 0; r < 4; ++r) frag[frag_off(mf_p2(st, rt, r), lane)] = -d[r];
   }
 }
 
@@ -1429,7 +1433,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
     for (int H = 0; H < 2; ++H) {
       const int q = 2 * k + H;                               // half index inside the group
-      const double* ldsH = lds + slot * kHalfDoubles + lane;
+      typedef double d2l __attribute__((ext_vector_type(2)));
+      const d2l* ldsP = (const d2l*)(lds + slot * kHalfDoubles) + lane;   // pair p of this half: ldsP[64 p]
       // the half fetched during this time slot is the one the leading wave group runs NEXT (slot index = q + lag):
       // ring position (q + lag + 1) mod 3, the one the trailing group left at the last barrier
       int slot_pre = slot + 1 + lag;
@@ -1457,7 +1462,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       double sc[4];                                           // a new tile between the transposition tile and its select
       unsigned long long dma_base = 0;                        // scalar base of the DMA instructions being issued
 #pragma unroll
-      for (int j = 0; j < kAhead; ++j) fq[j] = ldsH[j * 64];
+      for (int j = 0; j < kAhead / 2; ++j) {
+        const d2l t = ldsP[j * 64];
+        fq[2 * j] = t[0];
+        fq[2 * j + 1] = t[1];
+      }
 #pragma unroll
       for (int f = 0; f < ((dbg & 4) ? 8 : kHalfFrags); ++f) {
         // ---- this step's piece
@@ -1550,10 +1559,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
             ZT(rt) = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], ZT(rt), 0, 0, 0);
           }
         }
-        // ---- the fragments kAhead steps ahead take the registers the last two MFMAs have read (two per LDS instruction)
+        // ---- the fragments kAhead steps ahead take the registers the last two MFMAs have read (one 16-byte LDS read)
         if ((f & 1) && f + kAhead - 1 < kHalfFrags && !(dbg & 16)) {
-          fq[(f - 1) % kAhead] = ldsH[(f + kAhead - 1) * 64];
-          if (f + kAhead < kHalfFrags) fq[f % kAhead] = ldsH[(f + kAhead) * 64];
+          const d2l t = ldsP[((f + kAhead - 1) / 2) * 64];
+          fq[(f - 1) % kAhead] = t[0];
+          fq[f % kAhead] = t[1];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1685,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_bt2_wave(const double* __restrict__ sb_
   constexpr int kAhead = 8;
   double fq[kAhead];
 #pragma unroll
-  for (int j = 0; j < kAhead; ++j) fq[j] = frag[(size_t)j * 64 + lane];
+  for (int j = 0; j < kAhead; ++j) fq[j] = frag[frag_off(j, lane)];
   d4 wa = d4{0, 0, 0, 0};
 #pragma unroll
   for (int f = 0; f < kDiaFrags; ++f) {
@@ -1699,7 +1709,7 @@ __global__ __launch_bounds__(256) void k_bt2_wave(const double* __restrict__ sb_
       const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
       zt[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], zt[rt], 0, 0, 0);
     }
-    if (f + kAhead < kDiaFrags) fq[f % kAhead] = frag[(size_t)(f + kAhead) * 64 + lane];
+    if (f + kAhead < kDiaFrags) fq[f % kAhead] = frag[frag_off(f + kAhead, lane)];
   }
   // window back to memory
 #pragma unroll

@@ -38,7 +38,9 @@ def mfma(a_frag, b_frag, c):
 def steps():
     """Issue order of one diamond = order of the fragments in memory: for st = 3, 2, 1, 0:
     20 x ("p1", st, rt, r) with rt = st + j // 4, r = j % 4          (W = V_st^T Z; B operand = Z tile rt register r)
-    20 x ("p2", st, rt, r) with r = j // 5, rt = st + j % 5          (Z -= (V_st T_st) W; B operand = W register r)."""
+    20 x ("p2", st, rt, r) with r = j // 5, rt = st + j % 5          (Z -= (V_st T_st) W; B operand = W register r).
+    (In device memory the 64 lane values of fragments 2 p and 2 p + 1 are interleaved -- frag_off() in twostage.hip --
+    so that a lane fetches both with one 16-byte LDS read; the order of the fragments is the one modelled here.)"""
     out = []
     for st in (3, 2, 1, 0):
         out += [("p1", st, st + j // 4, j % 4) for j in range(20)]
