@@ -1036,9 +1036,6 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
 //     products consume them, 160 per diamond = 80 KB;
 //   * a workgroup streams the fragments into a ring of three half-diamond buffers (40 KB each) with LDS-DMA
 //     (global_load_lds_dwordx4, no staging registers), two halves ahead of the MFMAs; one barrier per half.
-#ifndef BT2_PRIO
-#define BT2_PRIO 0
-#endif
 #ifndef BT2_DBG
 #define BT2_DBG 0
 #endif
@@ -1370,9 +1367,25 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   static_assert(kDmaPer * NW == kDmaInstr && kDmaPer % 5 == 0, "DMA instructions are shared in fives");
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const unsigned voff = (unsigned)lane * 16u;
+  // 8 waves = two per SIMD: waves 4 .. 7 run one half-diamond behind waves 0 .. 3 (see the diamond loop)
+#ifndef BT2_LAGSEL
+#define BT2_LAGSEL 0   // experiments: 1 = odd waves trail instead of waves 4 .. 7, 2 = nobody trails
+#endif
+#ifndef BT2_DMA_H0
+#define BT2_DMA_H0 1   // experiment: 0 = every wave issues its share of the DMA in both halves
+#endif
+  constexpr bool kPhased = NW == 8 && BT2_LAGSEL != 2;
+  const int lag = (kPhased && (BT2_LAGSEL == 1 ? (wu & 1) != 0 : wu >= 4)) ? 1 : 0;
+  // DMA instructions a wave issues in a first / second half: with the phase offset exactly one wave group is in a first
+  // half during any time slot, and it issues ALL 40 (the first half is the piece-heavy one anyway; the partner's second
+  // half stays as bare as possible)
+  constexpr bool kDmaAllH0 = kPhased && BT2_LAGSEL == 0 && BT2_DMA_H0;
+  constexpr int kDmaH0 = kDmaAllH0 ? 2 * kDmaPer : kDmaPer, kDmaH1 = kDmaAllH0 ? 0 : kDmaPer;
+  const int dma_w = kDmaAllH0 ? (wu & 3) : wu;
+  constexpr int kFin0 = kDmaH0 == 5 ? 10 : 16;
   // M0 and the scalar base for instructions 5 g .. 5 g + 4 of this wave, half at `src`, ring slot `slot`
-  auto dma_begin = [&](const double* src, int slot, int g) -> unsigned long long {
-    const int qc = wu * kDmaPer + 5 * g + 2;
+  auto dma_begin = [&](const double* src, int slot, int g, int widx, int per) -> unsigned long long {
+    const int qc = widx * per + 5 * g + 2;
     const unsigned long long ga = (unsigned long long)(size_t)src + (unsigned long long)qc * 1024ull;
     // (the builtin returns int: widen through unsigned, or a low half with bit 31 set would smear into the high half)
     const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
@@ -1394,7 +1407,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     unsigned long long sbase = 0;
 #pragma unroll
     for (int j = 0; j < kDmaPer; ++j) {
-      if (j % 5 == 0) sbase = dma_begin(src, slot, j / 5);
+      if (j % 5 == 0) sbase = dma_begin(src, slot, j / 5, wu, kDmaPer);
       dma_go(sbase, j % 5);
     }
   };
@@ -1413,13 +1426,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   d4 zz[12];
   int fin_row = 0;
   bool have_fin = false;
-  // 8 waves = two per SIMD (w and w + 4): waves 4 .. 7 run one half-diamond behind waves 0 .. 3
-#ifndef BT2_LAGSEL
-#define BT2_LAGSEL 0   // experiments: 1 = odd waves trail instead of waves 4 .. 7, 2 = nobody trails
-#endif
-  constexpr bool kPhased = NW == 8 && BT2_LAGSEL != 2;
-  const int lag = (kPhased && (BT2_LAGSEL == 1 ? (wu & 1) != 0 : wu >= 4)) ? 1 : 0;
-  constexpr int kFin0 = NW == 8 ? 10 : 16;
+
   BT2_STAMP_DECL
   int S_cur = 0;   // (read by the -DBT2_TRACE build only)
   (void)S_cur;
@@ -1470,34 +1477,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #pragma unroll
       for (int f = 0; f < ((dbg & 4) ? 8 : kHalfFrags); ++f) {
         // ---- this step's piece
-#if BT2_PRIO == 1
-        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(2);
-        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(0);
-#elif BT2_PRIO == 2
-        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(2);
-        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(0);
-        if (H == 1 && f == 26) __builtin_amdgcn_s_setprio(1);
-        if (H == 1 && f == 52) __builtin_amdgcn_s_setprio(0);
-#elif BT2_PRIO == 3
-        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(0);
-        if (H == 0 && f == 44) __builtin_amdgcn_s_setprio(2);
-#elif BT2_PRIO == 4
-        if (H == 0 && f == 0) __builtin_amdgcn_s_setprio(3);
-        if (H == 0 && f == 72) __builtin_amdgcn_s_setprio(0);
-#endif
         // Two waves share a SIMD (w and w + 4) and the trailing one runs one half behind (lag): the pieces are placed
         // so that the partner of a wave in a piece-heavy stretch is in a stretch of (nearly) bare MFMAs and can keep
         // the matrix pipe fed -- the heavy pieces (DMA issue, the stores of the finished rows) sit in the first 40
         // steps of the FIRST half, which run beside the partner's second half, whose first 40 steps carry three light
         // pieces; the second 40 steps of both halves carry a few light ones each.
         if (H == 0) {
-          if (f < kDmaPer && !(dbg & 1)) {
-            if (f % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, f / 5);
+          if (f < kDmaH0 && !(dbg & 1)) {
+            if (f % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, f / 5, dma_w, kDmaH0);
             dma_go(dma_base, f % 5);
           }
         } else {
-          if (f >= 46 && f < 46 + kDmaPer && !(dbg & 1)) {
-            if ((f - 46) % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, (f - 46) / 5);
+          if (f >= 46 && f < 46 + kDmaH1 && !(dbg & 1)) {
+            if ((f - 46) % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, (f - 46) / 5, dma_w, kDmaH1);
             dma_go(dma_base, (f - 46) % 5);
           }
         }
@@ -1505,8 +1497,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           if (H == 0) {
             // rows entering at the slide, tiles 0 and 1: requested right after the half's DMA instructions (the compiler
             // does not see those: its vmcnt for the first use of a row then covers them, being older, and nothing younger)
-            if (f == kDmaPer + 1) load_raw(zn[0], win + 128);
-            if (f == kDmaPer + 3) load_raw(zn[1], win + 128 + 16);
+            if (f == kDmaH0 + 1) load_raw(zn[0], win + 128);
+            if (f == kDmaH0 + 3) load_raw(zn[1], win + 128 + 16);
             // rows finished at the last slide: tile i through the transposition tile at step 10 + 8 i (8 waves; 14 + 8 i
             // with the 10 DMA steps of the 4-wave variant), column halves a / b stored 4 and 6 steps later
             if (have_fin) {
@@ -1617,7 +1609,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     if (lag) {
       // time slot 0 of the trailing wave group: the leading group runs half 0; only this group's share of half 1's DMA
       if (!(dbg & 8)) barrier();
-      if (!(dbg & 1)) {
+      if (!(dbg & 1) && !kDmaAllH0) {
         dma_half(fgrp + (size_t)(1 < nh ? 1 : 0) * kHalfDoubles, 1);
       }
       wait_vm0();
