@@ -1192,7 +1192,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
                                                           const int* __restrict__ dia_off, double* __restrict__ z_all,
                                                           long long stride_z, int ncols, int batch, int xcd_map) {
   // ablation builds only (tools/ablate_bt2.sh; results are wrong by construction): 1 no fragment DMA, 2 no Z traffic,
-  // 4 one MFMA in ten, 8 no workgroup barriers in the diamond loop, 16 no fragment reads from LDS
+  // 4 one MFMA in ten, 8 no workgroup barriers in the diamond loop, 16 no fragment reads from LDS, 32 finished rows not
+  // stored, 64 entering rows not loaded / scattered, 128 finished rows transposed but not stored, 256 entering rows
+  // loaded but not scattered
   constexpr int dbg = BT2_DBG;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // ring of 3 half-diamond buffers | transposition tiles
   const int n = SL.n;
@@ -1371,6 +1373,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 #ifndef BT2_LAGSEL
 #define BT2_LAGSEL 0   // experiments: 1 = odd waves trail instead of waves 4 .. 7, 2 = nobody trails
 #endif
+#ifndef BT2_BURST
+#define BT2_BURST 0    // experiment: 1 = the heavy pieces of a first half in one burst in front of its first MFMA
+#endif
+#define PF(x) (BT2_BURST ? 0 : (x))
 #ifndef BT2_DMA_H0
 #define BT2_DMA_H0 1   // experiment: 0 = every wave issues its share of the DMA in both halves
 #endif
@@ -1464,7 +1470,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       // spends as long issuing its ~600 other instructions per half as the pipe needs for its 80 MFMAs, and the second
       // wave of the SIMD cannot fill the holes because it runs the same pattern.)
       d4 wa = d4{0, 0, 0, 0};
-      constexpr int kAhead = 8;                               // fragments in flight between LDS and the MFMA that uses them
+#ifndef BT2_KAHEAD
+#define BT2_KAHEAD 8
+#endif
+      constexpr int kAhead = BT2_KAHEAD;                      // fragments in flight between LDS and the MFMA that uses them
       double fq[kAhead];
       double sc[4];                                           // a new tile between the transposition tile and its select
       unsigned long long dma_base = 0;                        // scalar base of the DMA instructions being issued
@@ -1483,10 +1492,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
         // steps of the FIRST half, which run beside the partner's second half, whose first 40 steps carry three light
         // pieces; the second 40 steps of both halves carry a few light ones each.
         if (H == 0) {
+#if BT2_BURST
+          if (f == 0 && !(dbg & 1)) {
+#pragma unroll
+            for (int j = 0; j < kDmaH0; ++j) {
+              if (j % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, j / 5, dma_w, kDmaH0);
+              dma_go(dma_base, j % 5);
+            }
+          }
+#else
           if (f < kDmaH0 && !(dbg & 1)) {
             if (f % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, f / 5, dma_w, kDmaH0);
             dma_go(dma_base, f % 5);
           }
+#endif
         } else {
           if (f >= 46 && f < 46 + kDmaH1 && !(dbg & 1)) {
             if ((f - 46) % 5 == 0) dma_base = dma_begin(src_pre, slot_pre, (f - 46) / 5, dma_w, kDmaH1);
@@ -1497,34 +1516,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
           if (H == 0) {
             // rows entering at the slide, tiles 0 and 1: requested right after the half's DMA instructions (the compiler
             // does not see those: its vmcnt for the first use of a row then covers them, being older, and nothing younger)
-            if (f == kDmaH0 + 1) load_raw(zn[0], win + 128);
-            if (f == kDmaH0 + 3) load_raw(zn[1], win + 128 + 16);
+            if (f == PF(kDmaH0 + 1) && !(dbg & 64)) load_raw(zn[0], win + 128);
+            if (f == PF(kDmaH0 + 3) && !(dbg & 64)) load_raw(zn[1], win + 128 + 16);
             // rows finished at the last slide: tile i through the transposition tile at step 10 + 8 i (8 waves; 14 + 8 i
             // with the 10 DMA steps of the 4-wave variant), column halves a / b stored 4 and 6 steps later
-            if (have_fin) {
+            if (have_fin && !(dbg & 32)) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                if (f == kFin0 + 8 * i) tile_to_rows(ZT(8 + i), fin_rows);
-                if (f == kFin0 + 4 + 8 * i) store_rows_a(fin_rows, fin_row + 16 * i);
-                if (f == kFin0 + 6 + 8 * i) store_rows_b(fin_rows, fin_row + 16 * i);
+                if (f == PF(kFin0 + 8 * i)) tile_to_rows(ZT(8 + i), fin_rows);
+                if (dbg & 128) {   // (ablation: the transposition without the stores)
+                  if (f == PF(kFin0 + 4 + 8 * i)) asm volatile("" : : "v"(fin_rows.a), "v"(fin_rows.b));
+                } else {
+                  if (f == PF(kFin0 + 4 + 8 * i)) store_rows_a(fin_rows, fin_row + 16 * i);
+                  if (f == PF(kFin0 + 6 + 8 * i)) store_rows_b(fin_rows, fin_row + 16 * i);
+                }
               }
             }
             // tiles 0, 1 of the new rows into the spare array (free since step kFin0 + 24), then the requests for
             // tiles 2, 3 into the same two raw registers: the youngest four loads of the half, the only ones its closing
             // vmcnt(4) leaves in flight
-            if (f == 52) scatter_in(zn[0], sc, win + 128);
-            if (f == 58) scatter_out(ZT(8), sc, win + 128);
-            if (f == 60) scatter_in(zn[1], sc, win + 128 + 16);
-            if (f == 66) scatter_out(ZT(9), sc, win + 128 + 16);
-            if (f == 68) load_raw(zn[0], win + 128 + 32);
-            if (f == 70) load_raw(zn[1], win + 128 + 48);
+            if (f == 52 && (dbg & 256)) asm volatile("" : : "v"(zn[0].a), "v"(zn[0].b));
+            if (f == 52 && !(dbg & 64) && !(dbg & 256)) scatter_in(zn[0], sc, win + 128);
+            if (f == 58 && !(dbg & 64) && !(dbg & 256)) scatter_out(ZT(8), sc, win + 128);
+            if (f == 60 && (dbg & 256)) asm volatile("" : : "v"(zn[1].a), "v"(zn[1].b));
+            if (f == 60 && !(dbg & 64) && !(dbg & 256)) scatter_in(zn[1], sc, win + 128 + 16);
+            if (f == 66 && !(dbg & 64) && !(dbg & 256)) scatter_out(ZT(9), sc, win + 128 + 16);
+            if (f == 68 && !(dbg & 64)) load_raw(zn[0], win + 128 + 32);
+            if (f == 70 && !(dbg & 64)) load_raw(zn[1], win + 128 + 48);
           } else {
             // tiles 2, 3 (requested ~40 steps ago) before this half's DMA instructions are issued: the compiler's
             // vmcnt(0) for them must not cover the DMA
-            if (f == 28) scatter_in(zn[0], sc, win + 128 + 32);
-            if (f == 34) scatter_out(ZT(10), sc, win + 128 + 32);
-            if (f == 36) scatter_in(zn[1], sc, win + 128 + 48);
-            if (f == 42) scatter_out(ZT(11), sc, win + 128 + 48);
+            if (f == 28 && (dbg & 256)) asm volatile("" : : "v"(zn[0].a), "v"(zn[0].b));
+            if (f == 28 && !(dbg & 64) && !(dbg & 256)) scatter_in(zn[0], sc, win + 128 + 32);
+            if (f == 34 && !(dbg & 64) && !(dbg & 256)) scatter_out(ZT(10), sc, win + 128 + 32);
+            if (f == 36 && (dbg & 256)) asm volatile("" : : "v"(zn[1].a), "v"(zn[1].b));
+            if (f == 36 && !(dbg & 64) && !(dbg & 256)) scatter_in(zn[1], sc, win + 128 + 48);
+            if (f == 42 && !(dbg & 64) && !(dbg & 256)) scatter_out(ZT(11), sc, win + 128 + 48);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1564,7 +1591,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
       // this wave's part of the half fetched during this slot must have landed before the barrier that opens the next
       // slot (and the stores of the finished rows with it); after a first half the four youngest loads (new rows, tiles
       // 2 and 3) stay in flight
-      if (H == 0 && !(dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (H == 0 && !(dbg & 2) && !(dbg & 64)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else wait_vm0();
       slot = slot == 2 ? 0 : slot + 1;
     }
