@@ -2023,15 +2023,19 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SC_TRY(sc_side_streams(ctx, s1_parts - 1));
     SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
     for (int q = 1; q < s1_parts; ++q) SC_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[q - 1], ctx->aux_fork, 0));
-    for (int p = 0; p < npanels; ++p)
-      for (int q = 0; q < s1_parts; ++q) {
+    int rc_parts = SC_OK;
+    for (int p = 0; p < npanels && rc_parts == SC_OK; ++p)
+      for (int q = 0; q < s1_parts && rc_parts == SC_OK; ++q) {
         const int lo = (int)((long long)batch * q / s1_parts), hi = (int)((long long)batch * (q + 1) / s1_parts);
-        SC_TRY(run_panel(p, lo, hi, q == 0 ? st : ctx->side_streams[q - 1], q == 0));
+        rc_parts = run_panel(p, lo, hi, q == 0 ? st : ctx->side_streams[q - 1], q == 0);
       }
+    // (also after an error: the side streams are joined before anything returns, so that what they still have queued
+    // is ordered before whatever the caller enqueues next on the main stream)
     for (int q = 1; q < s1_parts; ++q) {
       SC_HIP(ctx, hipEventRecord(ctx->side_joins[q - 1], ctx->side_streams[q - 1]));
       SC_HIP(ctx, hipStreamWaitEvent(st, ctx->side_joins[q - 1], 0));
     }
+    SC_TRY(rc_parts);
   } else {
     for (int p = 0; p < npanels; ++p) SC_TRY(run_panel(p, 0, batch, st, true));
   }
