@@ -1,5 +1,4 @@
 """One-stage vs two-stage tridiagonalisation over (N, batch): ms per step of the whole solve.  python tools/crossover.py"""
-import os
 import subprocess
 import sys
 

@@ -1,5 +1,4 @@
 """Does the SYMV rate depend on where the matrix buffer sits?  Sweeps the base offset of the batch of matrices."""
-import ctypes as C
 import sys
 
 import numpy as np
