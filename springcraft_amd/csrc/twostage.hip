@@ -110,6 +110,18 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   const double* piv_in = sb + SL.qrpiv + (size_t)((j + 1) & 1) * (kB + 8);
   double* piv_out = sb + SL.qrpiv + (size_t)(j & 1) * (kB + 8);
 
+  // (1a) chunk -> registers, requested BEFORE the partial results of the previous launch are read and reduced (two
+  // dependent memory round trips become one; a launch of a blocked panel holds at most 9 columns = one pass)
+  const int ld_r = tid & (kQrRows - 1), ld_half = tid >> 7;
+  const int ld_rl = row_base + ld_r;
+  const double* ld_src = A + (size_t)j0 * n + r0 + std::min(ld_rl, m - 1);
+  const bool early = ncl <= 16;
+  double t_early[8];
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t_early[u] = ld_src[(size_t)std::min(c_lo + ld_half + 2 * u, kB - 1) * n];
+  }
+
   // (a0) reflector scalars and w
   if (j >= 1) {
     {
@@ -145,10 +157,15 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   // (1) chunk -> LDS: lanes along the rows (contiguous in memory)
   // (loads are unconditional, with clamped indices, and issued eight at a time: a load that is merged with a zero
   //  under a predicate makes hipcc wait for it before issuing the next one)
-  {
-    const int r = tid & (kQrRows - 1), half = tid >> 7;
-    const int rl = row_base + r;
-    const double* src = A + (size_t)j0 * n + r0 + std::min(rl, m - 1);
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c_lo + ld_half + 2 * u;
+      if (c < c_end) P[(c - c_lo) * LD + ld_r] = ld_rl < m ? t_early[u] : 0.0;
+    }
+  } else {
+    const int r = ld_r, half = ld_half, rl = ld_rl;
+    const double* src = ld_src;
     for (int c = c_lo + half; c < c_end; c += 16) {
       double t[8];
 #pragma unroll
@@ -494,8 +511,11 @@ __global__ __launch_bounds__(256) void k_sum_p2(double* __restrict__ sb_all, SbL
 
 // One workgroup per matrix: T (larft, forward columnwise) from tau and G = V^T V;  S = T^T (V^T X) T;
 // C = [T; T; -S/2]  (3 kB x kB, column-major), the right-hand factor of  W = [X1 | X2 | V] C.
-__global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri_all, TriLayout TL,
-                                                  double* __restrict__ sb_all, SbLayout SL, int j0) {
+__global__ __launch_bounds__(1024) void k_sb_small(const double* __restrict__ tri_all, TriLayout TL,
+                                                   double* __restrict__ sb_all, SbLayout SL, int j0) {
+  // One workgroup per matrix, on the critical path of every panel (QR -> SYMM -> Gram -> this -> W -> trailing update):
+  // 1024 threads and a T factor by halving (16 x 16 diagonal blocks by substitution, then T12 = -T11 G12 T22 twice)
+  // instead of 256 threads and larft's 64 dependent columns: 150-240 us -> see DESIGN section 7.
   constexpr int LD = kB + 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* G = sm;                 // [kB][LD]  G[i * LD + j]
@@ -504,13 +524,14 @@ __global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri
   double* U = T + kB * LD;
   const double* tri = tri_all + (size_t)blockIdx.x * TL.slab;
   double* sb = sb_all + (size_t)blockIdx.x * SL.slab;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   // the split-K product is (kB x 3 kB), column-major ld kB: columns [X1 | X2 | V]
   const double* prod = sb + SL.small;
   const size_t slice = (size_t)kB * 3 * kB;
-  for (int idx = tid; idx < kB * kB; idx += 256) {
+  for (int idx = tid; idx < kB * kB; idx += nthr) {
     const int i = idx & 63, jj = idx >> 6;
     double g = 0.0, x = 0.0;
+#pragma unroll
     for (int s = 0; s < kSmallSplit; ++s) {
       const double* ps = prod + s * slice;
       x += ps[i + (size_t)jj * kB] + ps[i + (size_t)(kB + jj) * kB];
@@ -521,18 +542,46 @@ __global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri
     T[i * LD + jj] = 0.0;
   }
   __syncthreads();
-  for (int qq = 0; qq < kB; ++qq) {
-    const double tau = tri[TL.tau + j0 + qq];
-    double s = 0.0;
-    if (tid < qq)
-      for (int l = tid; l < qq; ++l) s += T[tid * LD + l] * G[l * LD + qq];
+  // ---- T = the compact-WY factor of the panel's reflectors: (D + striu(G)) T = I row by row, i.e.
+  // T[i][c] = tau_i (delta_ic - sum_{l > i} G[i][l] T[l][c])  (larft's T; rows of tau = 0 reflectors come out zero).
+  // Diagonal 16 x 16 blocks: one thread per column, rows bottom-up, the column in registers.
+  if (tid < kB) {
+    const int bb = tid >> 4, c = tid & 15, o = bb * 16;
+    double x[16];
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double acc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int l = i + 1; l < 16; ++l) acc -= G[(o + i) * LD + o + l] * x[l];
+      x[i] = i <= c ? tri[TL.tau + j0 + o + i] * acc : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[(o + i) * LD + o + c] = x[i];
+  }
+  __syncthreads();
+  // off-diagonal blocks by halving: T12 = -T11 (G12 T22), block sizes 16 then 32 (U serves as the scratch for G12 T22)
+#pragma unroll
+  for (int bs = 16; bs <= 32; bs *= 2) {
+    const int npair = kB / (2 * bs);                 // 2 pairs of 16-blocks, then 1 pair of 32-blocks
+    for (int idx = tid; idx < npair * bs * bs; idx += nthr) {
+      const int pr = idx / (bs * bs), e = idx % (bs * bs), i = e / bs, jj = e % bs;
+      const int o1 = pr * 2 * bs, o2 = o1 + bs;
+      double acc = 0.0;
+      for (int l = 0; l <= jj; ++l) acc += G[(o1 + i) * LD + o2 + l] * T[(o2 + l) * LD + o2 + jj];   // T22 upper triangular
+      U[(o1 + i) * LD + o2 + jj] = acc;
+    }
     __syncthreads();
-    if (tid < qq) T[tid * LD + qq] = -tau * s;
-    if (tid == qq) T[qq * LD + qq] = tau;
+    for (int idx = tid; idx < npair * bs * bs; idx += nthr) {
+      const int pr = idx / (bs * bs), e = idx % (bs * bs), i = e / bs, jj = e % bs;
+      const int o1 = pr * 2 * bs, o2 = o1 + bs;
+      double acc = 0.0;
+      for (int l = i; l < bs; ++l) acc += T[(o1 + i) * LD + o1 + l] * U[(o1 + l) * LD + o2 + jj];    // T11 upper triangular
+      T[(o1 + i) * LD + o2 + jj] = -acc;
+    }
     __syncthreads();
   }
   // U = M1 T ; S = T^T U
-  for (int idx = tid; idx < kB * kB; idx += 256) {
+  for (int idx = tid; idx < kB * kB; idx += nthr) {
     const int i = idx >> 6, jj = idx & 63;
     double s = 0.0;
     for (int l = 0; l <= jj; ++l) s += M1[i * LD + l] * T[l * LD + jj];
@@ -540,7 +589,7 @@ __global__ __launch_bounds__(256) void k_sb_small(const double* __restrict__ tri
   }
   __syncthreads();
   double* cm = sb + SL.cmat;   // ld 3 kB
-  for (int idx = tid; idx < kB * kB; idx += 256) {
+  for (int idx = tid; idx < kB * kB; idx += nthr) {
     const int i = idx & 63, jj = idx >> 6;
     double s = 0.0;
     for (int l = 0; l <= i; ++l) s += T[l * LD + i] * U[l * LD + jj];
@@ -1996,7 +2045,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     }
     if (timed) t_symm.stop();
     SC_TRY(launch_gemm_f64(ctx, g + 2 * batch + lo, nb, kB, 3 * kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
-    hipLaunchKernelGGL(k_sb_small, dim3((unsigned)nb), dim3(256), lds_small, ps, tri_h, TL, sb_h, SL, j0);
+    hipLaunchKernelGGL(k_sb_small, dim3((unsigned)nb), dim3(1024), lds_small, ps, tri_h, TL, sb_h, SL, j0);
     if (nb == batch) {
       SC_TRY(launch_gemm_f64(ctx, g + 3 * batch, 2 * batch, m, kB, kGemmTile, 1, false, false, kGemmAmBk));
     } else {
