@@ -33,6 +33,11 @@ constexpr int kDiaSize = kDiaLd * kG;
 constexpr int kQrRows = 128;      // rows of the panel one k_panel_qr workgroup owns
 constexpr int kSmallSplit = 8;    // split-K of the V^T [X1|X2|V] product
 constexpr int kDescKinds = 9;     // GEMM records per panel and matrix (stage 1)
+#ifndef SC_QR_IB
+#define SC_QR_IB 8
+#endif
+constexpr int kIb = SC_QR_IB;     // inner block of the blocked panel QR (columns whose reflectors are applied to the rest at once)
+constexpr int kEarly = (kIb + 2) / 2;   // column loads per thread that cover a launch of an inner block (kIb + 1 columns)
 
 struct HH {
   double beta, tau, scale;
@@ -115,11 +120,11 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   const int ld_r = tid & (kQrRows - 1), ld_half = tid >> 7;
   const int ld_rl = row_base + ld_r;
   const double* ld_src = A + (size_t)j0 * n + r0 + std::min(ld_rl, m - 1);
-  const bool early = ncl <= 16;
-  double t_early[8];
+  const bool early = ncl <= 2 * kEarly;
+  double t_early[kEarly];
   if (early) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t_early[u] = ld_src[(size_t)std::min(c_lo + ld_half + 2 * u, kB - 1) * n];
+    for (int u = 0; u < kEarly; ++u) t_early[u] = ld_src[(size_t)std::min(c_lo + ld_half + 2 * u, kB - 1) * n];
   }
 
   // (a0) reflector scalars and w
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
   //  under a predicate makes hipcc wait for it before issuing the next one)
   if (early) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kEarly; ++u) {
       const int c = c_lo + ld_half + 2 * u;
       if (c < c_end) P[(c - c_lo) * LD + ld_r] = ld_rl < m ? t_early[u] : 0.0;
     }
@@ -253,7 +258,6 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
 //   M[i][c] = v_{c0+i} . P[:, c]  for c = c0 .. kB-1  (the first 8 columns are the Gram matrix of the block's reflectors).
 // k_pqr_blk_b: sums them, builds the 8 x 8 T factor, W = T^T M, updates P[:, c] -= V W for c >= c0+8 and leaves the
 //   tail Gram row / pivot row of column c0+8 for the next inner block's first column launch.
-constexpr int kIb = 8;
 
 // explicit form of the inner block's reflectors in the LDS copy of chunk 0 (memory keeps R above the pivots)
 __device__ __forceinline__ void blk_explicit_v(double* P, int LD, int c0, int ncols, int row_base) {
@@ -483,6 +487,254 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
     const int rl = row_base + r;
     if (rl < m)
       for (int cc = jn + half; cc < kB; cc += 2) A[(size_t)(j0 + cc) * n + r0 + rl] = P[(cc - c0) * LD + r];
+  }
+}
+
+// ---- the whole panel QR in ONE workgroup per matrix (panels of at most 1024 RU rows) -----------------------------------
+// The launches above exist because a column's reflector needs sums over all rows, i.e. over all 128-row chunks: 80
+// dependent launches per panel, 10 - 22 us each, the longest item of a latency-bound solve (C4: 4700 launches per
+// step).  Here 1024 threads own the rows of the panel (thread t: rows t, t + 1024, ...), the 8 columns of an inner block
+// live in registers, and every sum over the rows is a wave reduction + 16 partials in LDS + two workgroup barriers
+// (~1 us instead of a launch).  Same arithmetic as the launches above (tail Gram row + pivot row per column, the inner
+// block's reflectors applied to the rest of the panel as one block update), other reduction trees.
+// One workgroup streams its panel at the rate of one CU: the path is for batches (the matrices run side by side) and
+// panels of at most 4096 rows; larger panels and single large matrices keep the chunked launches.
+constexpr int kWgThreads = 1024, kWgWaves = kWgThreads / 64;
+
+// Sums of eight values over the 64 lanes with 10 exchanges instead of 48: three halving steps (a lane keeps half of its
+// values and receives the partner's sums of those), then three plain steps.  The first two halving steps (six of the ten
+// exchanges) pair neighbouring lanes and are DPP moves on the vector ALU; the rest go through the LDS crossbar, which
+// all 16 waves of the workgroup share and which bounds the kernel.  Lane l < 8 returns the total of v[wave_reduce8_index(l)].
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ int wave_reduce8_index(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+__device__ __forceinline__ double wave_reduce8(const double (&v)[8]) {
+  const int lane = threadIdx.x & 63;
+  double k4[4], k2[2];
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double send = b0 ? v[k] : v[k + 4];
+    k4[k] = (b0 ? v[k + 4] : v[k]) + dpp_quad<0xB1>(send);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double send = b1 ? k4[k] : k4[k + 2];
+    k2[k] = (b1 ? k4[k + 2] : k4[k]) + dpp_quad<0x4E>(send);    // quad_perm [2, 3, 0, 1]: lane ^ 2
+  }
+  const double send = b2 ? k2[0] : k2[1];
+  double r = (b2 ? k2[1] : k2[0]) + __shfl_xor(send, 4);
+  r += __shfl_xor(r, 8);
+  r += __shfl_xor(r, 16);
+  r += __shfl_xor(r, 32);
+  return r;
+}
+
+template <int RU, int CU>
+__global__ __launch_bounds__(1024) void k_panel_wg(double* __restrict__ a_all, long long stride_a,
+                                                   double* __restrict__ tri_all, TriLayout TL,
+                                                   double* __restrict__ sb_all, SbLayout SL, int j0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* red = sm;                               // [kWgWaves][8]   wave partials of the per-column sums
+  double* fin = red + kWgWaves * 8;               // [2][8]          their totals (double-buffered by column parity)
+  double* piv = fin + 16;                         // [2][8]          pivot row of the inner block
+  double* tauL = piv + 16;                        // [8]
+  double* Ms = tauL + 8;                          // [8][kB]         M = V^T P, then W = T^T M (column index = panel column)
+  double* Tf = Ms + 8 * kB;                       // [8][8]
+  double* part = Tf + 64;                         // [kWgWaves][kB][8] wave partials of M
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  double* A = a_all + (size_t)blockIdx.x * stride_a;
+  double* tri = tri_all + (size_t)blockIdx.x * TL.slab;
+  double* sb = sb_all + (size_t)blockIdx.x * SL.slab;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* P = A + (size_t)j0 * n + r0;            // P(r, c) = P[c * n + r]
+  int rl[RU], rc[RU];                             // my rows, and the same clamped into the panel for the loads
+  bool ok[RU];
+#pragma unroll
+  for (int u = 0; u < RU; ++u) { rl[u] = tid + kWgThreads * u; ok[u] = rl[u] < m; rc[u] = std::min(rl[u], m - 1); }
+  // accesses = a column's (uniform, scalar) base + the row's 32-bit byte offset, re-materialised at the access so that
+  // the compiler does not hoist RU x 64 per-column vector addresses out of the loops (they would not fit the registers)
+  typedef char __attribute__((address_space(1)))* gbp;
+  typedef double __attribute__((address_space(1)))* gdp;
+  typedef const double __attribute__((address_space(1)))* gdp_c;
+  auto off = [&](int row) -> unsigned {
+    unsigned e = 8u * (unsigned)row;
+    asm volatile("" : "+v"(e));
+    return e;
+  };
+  auto ld = [&](const double* colbase, int row) -> double { return *(gdp_c)((gbp)colbase + off(row)); };
+  auto st = [&](double* colbase, int row, double val) { *(gdp)((gbp)colbase + off(row)) = val; };
+
+  for (int c0 = 0; c0 < kB; c0 += 8) {
+    // ---- the inner block's columns -> registers
+    double x[RU][8];
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[u][i] = ld(P + (size_t)(c0 + i) * n, rc[u]);
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[u][i] = ok[u] ? x[u][i] : 0.0;
+    // ---- its 8 reflectors
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = c0 + jj;                      // pivot = local row j, owned by thread j (u = 0)
+      const int pb = jj & 1;
+      double g[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double acc = 0.0;
+        if (c >= jj) {
+#pragma unroll
+          for (int u = 0; u < RU; ++u) acc += rl[u] > j ? x[u][jj] * x[u][c] : 0.0;
+        }
+        g[c] = acc;
+      }
+      const double gs = wave_reduce8(g);
+      if (lane < 8) red[wv * 8 + wave_reduce8_index(lane)] = gs;
+      if (tid == j) {
+#pragma unroll
+        for (int c = jj; c < 8; ++c) piv[pb * 8 + c] = x[0][c];
+      }
+      __syncthreads();
+      if (tid < 8) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWgWaves; ++w2) acc += red[w2 * 8 + tid];
+        fin[pb * 8 + tid] = acc;
+      }
+      __syncthreads();
+      const HH h = householder(piv[pb * 8 + jj], fin[pb * 8 + jj]);
+      if (tid == 0) { tri[TL.tau + j0 + j] = h.tau; tauL[jj] = h.tau; }
+      double v[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) v[u] = rl[u] > j ? h.scale * x[u][jj] : (rl[u] == j ? 1.0 : 0.0);
+#pragma unroll
+      for (int c = jj + 1; c < 8; ++c) {
+        const double wc = h.tau * (piv[pb * 8 + c] + h.scale * fin[pb * 8 + c]);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) x[u][c] -= v[u] * wc;
+      }
+      // column j is final: R entries of this inner block above the pivot, beta at it, v below; V in its explicit form
+      // stays in the registers and goes to the three panel buffers
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (ok[u]) {
+          if (rl[u] >= c0) st(P + (size_t)j * n, rl[u], rl[u] > j ? v[u] : (rl[u] == j ? h.beta : x[u][jj]));
+          st(sb + SL.vw + (size_t)j * n + r0, rl[u], v[u]);
+          st(sb + SL.wv + (size_t)(kB + j) * n + r0, rl[u], v[u]);
+          st(sb + SL.xv + (size_t)(2 * kB + j) * n + r0, rl[u], v[u]);
+        }
+        x[u][jj] = ok[u] ? v[u] : 0.0;
+      }
+    }
+    const int jn = c0 + 8;                        // first column to the right of the inner block
+    if (jn >= kB) break;
+    // ---- M[i][c] = v_i . P[:, c]: first the block's own columns (the Gram matrix of its reflectors), then the columns
+    // to the right, CU at a time so that their loads are in flight together; wave partials -> LDS, summed below
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+      double pr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) acc += x[u][i] * x[u][ci];
+        pr[i] = acc;
+      }
+      const double ps = wave_reduce8(pr);
+      if (lane < 8) part[((size_t)wv * kB + c0 + ci) * 8 + wave_reduce8_index(lane)] = ps;
+    }
+    for (int cb = jn; cb < kB; cb += CU) {
+      double a[CU][RU];
+#pragma unroll
+      for (int k = 0; k < CU; ++k)
+#pragma unroll
+        for (int u = 0; u < RU; ++u) a[k][u] = ld(P + (size_t)std::min(cb + k, kB - 1) * n, rc[u]);
+#pragma unroll
+      for (int k = 0; k < CU; ++k) {
+        double pr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int u = 0; u < RU; ++u) acc += ok[u] ? x[u][i] * a[k][u] : 0.0;
+          pr[i] = acc;
+        }
+        const double ps = wave_reduce8(pr);
+        if (lane < 8 && cb + k < kB) part[((size_t)wv * kB + cb + k) * 8 + wave_reduce8_index(lane)] = ps;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 8 * (kB - c0); idx += kWgThreads) {
+      const int i = idx & 7, c = c0 + (idx >> 3);
+      double acc = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < kWgWaves; ++w2) acc += part[((size_t)w2 * kB + c) * 8 + i];
+      Ms[i * kB + c] = acc;
+    }
+    __syncthreads();
+    // T (larft, forward columnwise) of the inner block: G[l][q] = Ms[l][c0 + q]
+    if (tid == 0) {
+      for (int qq = 0; qq < 8; ++qq) {
+        const double tau = tauL[qq];
+        for (int a2 = 0; a2 < qq; ++a2) {
+          double s2 = 0.0;
+          for (int l = a2; l < qq; ++l) s2 += Tf[a2 * 8 + l] * Ms[l * kB + c0 + qq];
+          Tf[a2 * 8 + qq] = -tau * s2;
+        }
+        Tf[qq * 8 + qq] = tau;
+        for (int a2 = qq + 1; a2 < 8; ++a2) Tf[a2 * 8 + qq] = 0.0;
+      }
+    }
+    __syncthreads();
+    // W = T^T M for the columns to the right (in place, one thread per column)
+    if (tid >= jn && tid < kB) {
+      double mcol[8], wcol[8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) mcol[l] = Ms[l * kB + tid];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int l = 0; l <= i; ++l) s2 += Tf[l * 8 + i] * mcol[l];
+        wcol[i] = s2;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Ms[i * kB + tid] = wcol[i];
+    }
+    __syncthreads();
+    // P[:, c] -= V W[:, c]
+    for (int cb = jn; cb < kB; cb += CU) {
+      double a[CU][RU];
+#pragma unroll
+      for (int k = 0; k < CU; ++k)
+#pragma unroll
+        for (int u = 0; u < RU; ++u) a[k][u] = ld(P + (size_t)std::min(cb + k, kB - 1) * n, rc[u]);
+#pragma unroll
+      for (int k = 0; k < CU; ++k) {
+        const int c = std::min(cb + k, kB - 1);
+        double wcol[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wcol[i] = Ms[i * kB + c];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s2 += x[u][i] * wcol[i];
+          if (ok[u] && rl[u] >= c0 && cb + k < kB) st(P + (size_t)c * n, rl[u], a[k][u] - s2);
+        }
+      }
+    }
+    __syncthreads();   // (the next inner block reads what this thread has just written to the same rows; the barrier
+                       // separates the reuse of the LDS buffers)
   }
 }
 
@@ -1831,7 +2083,7 @@ size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
   L.xsplit = L.symm_split > 1 ? take((long long)2 * L.symm_split * n * kB) : 0;
   L.qrpart = take((long long)2 * nchunk * kB);
   L.qrpiv = take(2 * (kB + 8));
-  L.qrpart8 = take((long long)nchunk * 8 * kB);
+  L.qrpart8 = take((long long)nchunk * kIb * kB);
   L.small = take((long long)kSmallSplit * kB * 3 * kB);
   L.cmat = take(3 * kB * kB);
   L.small2 = take((long long)kSmallSplit * 2 * kB * kB);
@@ -2014,7 +2266,19 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SbLayout SQ = SL;     // where the panel QR leaves V: the second panel of a pair uses the second half of [V|W..], [W|V..]
     if (rl == 2) { SQ.vw += (long long)2 * kB * n; SQ.wv += (long long)2 * kB * n; }
     if (timed) t_qr.start();
-    if (nr == kB && blocked_qr) {
+    // (one workgroup per matrix while the panel is short enough for its rows to sit in the registers of 1024 threads and
+    // there are matrices enough to run side by side; SPRINGCRAFT_QR_WG = 0 / 1 forces the chunked launches / this path)
+    static const int env_wg = [] { const char* e = getenv("SPRINGCRAFT_QR_WG"); return e ? atoi(e) : -1; }();
+    const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0 && (env_wg == 1 || nb >= 4);
+    if (use_wg) {
+      const size_t lds_wg = sizeof(double) * (size_t)(kWgWaves * 8 + 16 + 16 + 8 + 8 * kB + 64 + kWgWaves * kB * 8);
+      const int ru = (m + kWgThreads - 1) / kWgThreads;
+      const dim3 g1((unsigned)nb), b1((unsigned)kWgThreads);
+      if (ru <= 1) hipLaunchKernelGGL((k_panel_wg<1, 8>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+      else if (ru == 2) hipLaunchKernelGGL((k_panel_wg<2, 8>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+      else if (ru == 3) hipLaunchKernelGGL((k_panel_wg<3, 4>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+      else hipLaunchKernelGGL((k_panel_wg<4, 2>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+    } else if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
       hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, 0, nr, kIb);
       for (int c0 = 0; c0 < kB; c0 += kIb) {
