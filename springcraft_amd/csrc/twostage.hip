@@ -2266,10 +2266,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     SbLayout SQ = SL;     // where the panel QR leaves V: the second panel of a pair uses the second half of [V|W..], [W|V..]
     if (rl == 2) { SQ.vw += (long long)2 * kB * n; SQ.wv += (long long)2 * kB * n; }
     if (timed) t_qr.start();
-    // (one workgroup per matrix while the panel is short enough for its rows to sit in the registers of 1024 threads and
-    // there are matrices enough to run side by side; SPRINGCRAFT_QR_WG = 0 / 1 forces the chunked launches / this path)
+    // (one workgroup per matrix while the panel is short enough for its rows to sit in the registers of 1024 threads --
+    // also for a single matrix: N = 512 two-stage 45 -> 37 ms; SPRINGCRAFT_QR_WG = 0 keeps the chunked launches)
     static const int env_wg = [] { const char* e = getenv("SPRINGCRAFT_QR_WG"); return e ? atoi(e) : -1; }();
-    const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0 && (env_wg == 1 || nb >= 4);
+    const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0;
     if (use_wg) {
       const size_t lds_wg = sizeof(double) * (size_t)(kWgWaves * 8 + 16 + 16 + 8 + 8 * kB + 64 + kWgWaves * kB * 8);
       const int ru = (m + kWgThreads - 1) / kWgThreads;

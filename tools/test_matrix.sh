@@ -15,3 +15,4 @@ run SPRINGCRAFT_QR_UNBLOCKED=1
 run SPRINGCRAFT_SYMM_SPLIT=4 SPRINGCRAFT_BT2_WAVE=1
 run SPRINGCRAFT_BT2_WAVE=0
 run SPRINGCRAFT_PANEL_PAIRS=0
+run SPRINGCRAFT_QR_WG=0
