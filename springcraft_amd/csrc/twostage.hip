@@ -502,9 +502,8 @@ __global__ __launch_bounds__(256) void k_pqr_blk_b(double* __restrict__ a_all, l
 constexpr int kWgThreads = 1024, kWgWaves = kWgThreads / 64;
 
 // Sums of eight values over the 64 lanes with 10 exchanges instead of 48: three halving steps (a lane keeps half of its
-// values and receives the partner's sums of those), then three plain steps.  The first two halving steps (six of the ten
-// exchanges) pair neighbouring lanes and are DPP moves on the vector ALU; the rest go through the LDS crossbar, which
-// all 16 waves of the workgroup share and which bounds the kernel.  Lane l < 8 returns the total of v[wave_reduce8_index(l)].
+// values and receives the partner's sums of those), then three plain steps.  The exchanges inside a row of 16 lanes (eight of the ten) are DPP
+// moves on the vector ALU; the two across rows go through the LDS crossbar, which all 16 waves of the workgroup share.  Lane l < 8 returns the total of v[wave_reduce8_index(l)].
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double x) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -528,8 +527,9 @@ __device__ __forceinline__ double wave_reduce8(const double (&v)[8]) {
     k2[k] = (b1 ? k4[k + 2] : k4[k]) + dpp_quad<0x4E>(send);    // quad_perm [2, 3, 0, 1]: lane ^ 2
   }
   const double send = b2 ? k2[0] : k2[1];
-  double r = (b2 ? k2[1] : k2[0]) + __shfl_xor(send, 4);
-  r += __shfl_xor(r, 8);
+  const double from_lo = dpp_quad<0x114>(send), from_hi = dpp_quad<0x104>(send);   // row_shr:4 (lane - 4), row_shl:4 (lane + 4)
+  double r = (b2 ? k2[1] : k2[0]) + (b2 ? from_lo : from_hi);                      // lane ^ 4
+  r += dpp_quad<0x128>(r);                                                         // row_ror:8 = lane ^ 8 inside a row of 16
   r += __shfl_xor(r, 16);
   r += __shfl_xor(r, 32);
   return r;
