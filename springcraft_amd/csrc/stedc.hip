@@ -506,6 +506,7 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
   unsigned long long t_b = hi_b - ((hi_b - lo_b) >> 1);
   if (t_start > 0.0) t_b = (unsigned long long)__double_as_longlong(t_start);
   unsigned long long probe_dist = 4ull;
+  double t_accept = 0.0;
   for (int it = 0; it < 90 && hi_b - lo_b > 1ull; ++it) {
     const double t = __longlong_as_double((long long)t_b);
     double fp;
@@ -524,6 +525,17 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
       if (c_b > lo_b && c_b < hi_b) {
         n_b = c_b;
         const unsigned long long step = c_b > t_b ? c_b - t_b : t_b - c_b;
+#ifndef DC_STRICT_BRACKET
+        if (step <= 2ull) {
+          // the iteration moves by at most two ulps of t: t is the root to that accuracy (the step is quadratically small
+          // long before it is that small).  Taken as it is -- closing the bracket to neighbouring doubles from the far
+          // side and comparing |f| at its two ends cost four more evaluations of ~ nine (LAPACK's dlaed4 also stops on a
+          // bound for |f|, not on a closed bracket); the eigenvectors are built from the roots by the Gu-Eisenstat
+          // weights, which make them orthogonal for whatever roots they are given.
+          t_accept = tn;
+          break;
+        }
+#endif
         if (step <= 4ull) {
           // converged from one side: look a few ulps beyond (4, 32, 256, ...) on the side the bracket is still wide
           const unsigned long long far = go_up ? c_b + probe_dist : (c_b > probe_dist ? c_b - probe_dist : 0ull);
@@ -535,7 +547,9 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
     t_b = n_b;
   }
   double t_best = __longlong_as_double((long long)hi_b);
-  if (lo_b > 0ull) {
+  if (t_accept > 0.0) {
+    t_best = t_accept;
+  } else if (lo_b > 0ull) {
     const double t_lo = __longlong_as_double((long long)lo_b);
     const double f_lo = fabs(fsum(dorg, positive ? t_lo : -t_lo));
     const double f_hi = fabs(fsum(dorg, positive ? t_best : -t_best));

@@ -460,6 +460,7 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
   int org;
   bool positive;      // tau > 0 (origin is the lower pole) or tau < 0 (origin is the upper pole)
   double t_hi;        // bracket for |tau|: (0, t_hi]
+  double t_start = 0.0;   // first iterate (0: the bit midpoint of the bracket)
   if (j == K - 1) {
     org = K - 1;
     positive = true;
@@ -474,6 +475,25 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
     const double fm = fsum(dl[j], half);
     if (fm > 0.0) { org = j; positive = true; } else { org = j + 1; positive = false; }
     t_hi = half;
+    // First iterate as LAPACK's dlaed4 takes it: the two poles next to the root kept exactly, the rest of f frozen at
+    // the midpoint (c = f(mid) without the two terms) -- a quadratic in tau.  It only replaces the bit midpoint of the
+    // bracket as the starting point (two to three evaluations fewer); every safeguard below is unchanged.
+    {
+      const double zj2 = z2 ? z2[j] : zzg[j] * zzg[j];
+      const double zk2 = z2 ? z2[j + 1] : zzg[j + 1] * zzg[j + 1];
+      const double c = fm + (zj2 - zk2) / half;
+      double t0;
+      if (positive) {
+        const double a = c * gap + zj2 + zk2, b = zj2 * gap;
+        const double disc = sqrt(fabs(a * a - 4.0 * b * c));
+        t0 = a > 0.0 ? 2.0 * b / (a + disc) : (a - disc) / (2.0 * c);
+      } else {
+        const double a = -c * gap + zj2 + zk2, b = -zk2 * gap;
+        const double disc = sqrt(fabs(a * a + 4.0 * b * c));
+        t0 = -(a < 0.0 ? 2.0 * b / (a - disc) : -(a + disc) / (2.0 * c));   // |tau|, tau <= 0
+      }
+      if (t0 == t0 && t0 > 0.0 && t0 < t_hi) t_start = t0;
+    }
   }
   const double dorg = dl[org];
   // Root of f in t = |tau| on (0, t_hi], kept in a bracket [lo_b, hi_b] of IEEE bit patterns (monotone map, so the
@@ -484,6 +504,7 @@ __global__ __launch_bounds__(1024) void k_dc_secular(double* __restrict__ dc_all
   // closes to neighbouring doubles: same end state as plain bisection, in ~10 evaluations instead of ~62.
   unsigned long long lo_b = 0ull, hi_b = (unsigned long long)__double_as_longlong(t_hi);
   unsigned long long t_b = hi_b - ((hi_b - lo_b) >> 1);
+  if (t_start > 0.0) t_b = (unsigned long long)__double_as_longlong(t_start);
   unsigned long long probe_dist = 4ull;
   for (int it = 0; it < 90 && hi_b - lo_b > 1ull; ++it) {
     const double t = __longlong_as_double((long long)t_b);
