@@ -2462,9 +2462,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       SC_TRY(sc_side_streams(ctx, nparts - 1));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
       for (int p = 1; p < nparts; ++p) SC_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[p - 1], ctx->aux_fork, 0));
-      // launches go out in bursts of 16 wavefronts per stream rather than alternating streams launch by launch: the host
-      // needs ~11-13 us per launch and three parts x 12 k launches are close to the stage's own time (451 -> 434 ms)
-      static const int burst = [] { const char* e = getenv("SPRINGCRAFT_BULGE_BURST"); return e ? std::max(1, atoi(e)) : 16; }();
+      // launches go out in bursts of 32 wavefronts per stream rather than alternating streams launch by launch: the host
+      // needs ~11-13 us per launch and three parts x 12 k launches are close to the stage's own time (451 -> 434 ms with
+      // bursts of 16; round 3, same-box A/B on two boxes: 8 / 16 / 32 / 64 -> 465 / 464 / 421 / 463 and 437-467 / 430-434)
+      static const int burst = [] { const char* e = getenv("SPRINGCRAFT_BULGE_BURST"); return e ? std::max(1, atoi(e)) : 32; }();
       for (int t0 = 0; t0 <= t_max; t0 += burst)
         for (int p = 0; p < nparts; ++p) {
           const int lo = (int)((long long)batch * p / nparts), hi = (int)((long long)batch * (p + 1) / nparts);
