@@ -540,13 +540,11 @@ __global__ __launch_bounds__(1024) void k_panel_wg(double* __restrict__ a_all, l
                                                    double* __restrict__ tri_all, TriLayout TL,
                                                    double* __restrict__ sb_all, SbLayout SL, int j0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* red = sm;                               // [kWgWaves][8]   wave partials of the per-column sums
-  double* fin = red + kWgWaves * 8;               // [2][8]          their totals (double-buffered by column parity)
-  double* piv = fin + 16;                         // [2][8]          pivot row of the inner block
+  double* red = sm;                               // [2][kWgWaves][8] wave partials of the per-column sums (by column parity)
+  double* piv = red + 2 * kWgWaves * 8;           // [2][8]          pivot row of the inner block
   double* tauL = piv + 16;                        // [8]
   double* Ms = tauL + 8;                          // [8][kB]         M = V^T P, then W = T^T M (column index = panel column)
-  double* Tf = Ms + 8 * kB;                       // [8][8]
-  double* part = Tf + 64;                         // [kWgWaves][kB][8] wave partials of M
+  double* part = Ms + 8 * kB;                         // [kWgWaves][kB][8] wave partials of M
   const int n = TL.n;
   const int r0 = j0 + kB, m = n - r0;
   double* A = a_all + (size_t)blockIdx.x * stride_a;
@@ -598,27 +596,35 @@ __global__ __launch_bounds__(1024) void k_panel_wg(double* __restrict__ a_all, l
         g[c] = acc;
       }
       const double gs = wave_reduce8(g);
-      if (lane < 8) red[wv * 8 + wave_reduce8_index(lane)] = gs;
+      if (lane < 8) red[(pb * kWgWaves + wv) * 8 + wave_reduce8_index(lane)] = gs;
       if (tid == j) {
 #pragma unroll
         for (int c = jj; c < 8; ++c) piv[pb * 8 + c] = x[0][c];
       }
-      __syncthreads();
-      if (tid < 8) {
-        double acc = 0.0;
+      __syncthreads();   // (ONE barrier per column: the partials and the pivot row are double-buffered by its parity)
+      // totals: lane c < 8 of every wave sums the 16 partials of value c (same order in every wave), the others take them
+      // from that lane through a scalar register
+      double tot = 0.0;
+      if (lane < 8) {
 #pragma unroll
-        for (int w2 = 0; w2 < kWgWaves; ++w2) acc += red[w2 * 8 + tid];
-        fin[pb * 8 + tid] = acc;
+        for (int w2 = 0; w2 < kWgWaves; ++w2) tot += red[(pb * kWgWaves + w2) * 8 + lane];
       }
-      __syncthreads();
-      const HH h = householder(piv[pb * 8 + jj], fin[pb * 8 + jj]);
+      double fin[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(tot);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tb, c);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), c);
+        fin[c] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+      }
+      const HH h = householder(piv[pb * 8 + jj], fin[jj]);
       if (tid == 0) { tri[TL.tau + j0 + j] = h.tau; tauL[jj] = h.tau; }
       double v[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) v[u] = rl[u] > j ? h.scale * x[u][jj] : (rl[u] == j ? 1.0 : 0.0);
 #pragma unroll
       for (int c = jj + 1; c < 8; ++c) {
-        const double wc = h.tau * (piv[pb * 8 + c] + h.scale * fin[pb * 8 + c]);
+        const double wc = h.tau * (piv[pb * 8 + c] + h.scale * fin[c]);
 #pragma unroll
         for (int u = 0; u < RU; ++u) x[u][c] -= v[u] * wc;
       }
@@ -681,31 +687,17 @@ __global__ __launch_bounds__(1024) void k_panel_wg(double* __restrict__ a_all, l
       Ms[i * kB + c] = acc;
     }
     __syncthreads();
-    // T (larft, forward columnwise) of the inner block: G[l][q] = Ms[l][c0 + q]
-    if (tid == 0) {
-      for (int qq = 0; qq < 8; ++qq) {
-        const double tau = tauL[qq];
-        for (int a2 = 0; a2 < qq; ++a2) {
-          double s2 = 0.0;
-          for (int l = a2; l < qq; ++l) s2 += Tf[a2 * 8 + l] * Ms[l * kB + c0 + qq];
-          Tf[a2 * 8 + qq] = -tau * s2;
-        }
-        Tf[qq * 8 + qq] = tau;
-        for (int a2 = qq + 1; a2 < 8; ++a2) Tf[a2 * 8 + qq] = 0.0;
-      }
-    }
-    __syncthreads();
-    // W = T^T M for the columns to the right (in place, one thread per column)
+    // W = T^T M for the columns to the right without forming T: (D + striu(G))^T W = M with D = diag(1 / tau) and
+    // G[l][i] = Ms[l][c0 + i] the Gram matrix of the block's reflectors, i.e. W[i] = tau_i (M[i] - sum_{l < i} G[l][i] W[l])
+    // (rows of tau = 0 reflectors come out zero, as in larft's T); one thread per column, in place
     if (tid >= jn && tid < kB) {
-      double mcol[8], wcol[8];
-#pragma unroll
-      for (int l = 0; l < 8; ++l) mcol[l] = Ms[l * kB + tid];
+      double wcol[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        double s2 = 0.0;
+        double acc = Ms[i * kB + tid];
 #pragma unroll
-        for (int l = 0; l <= i; ++l) s2 += Tf[l * 8 + i] * mcol[l];
-        wcol[i] = s2;
+        for (int l = 0; l < i; ++l) acc -= Ms[l * kB + c0 + i] * wcol[l];
+        wcol[i] = tauL[i] * acc;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) Ms[i * kB + tid] = wcol[i];
@@ -2271,7 +2263,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     static const int env_wg = [] { const char* e = getenv("SPRINGCRAFT_QR_WG"); return e ? atoi(e) : -1; }();
     const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0;
     if (use_wg) {
-      const size_t lds_wg = sizeof(double) * (size_t)(kWgWaves * 8 + 16 + 16 + 8 + 8 * kB + 64 + kWgWaves * kB * 8);
+      const size_t lds_wg = sizeof(double) * (size_t)(2 * kWgWaves * 8 + 16 + 8 + 8 * kB + kWgWaves * kB * 8);
       const int ru = (m + kWgThreads - 1) / kWgThreads;
       const dim3 g1((unsigned)nb), b1((unsigned)kWgThreads);
       if (ru <= 1) hipLaunchKernelGGL((k_panel_wg<1, 8>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
