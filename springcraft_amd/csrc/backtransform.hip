@@ -148,7 +148,10 @@ int bt_desc_count(int n, int batch) {
 // d_a is modified (cleaned); d_vt: (batch, n, n) scratch that receives V T.
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, const double* d_tri_ws,
                           const TriLayout& TL, double* d_bt_ws, const BtLayout& BL, double* d_z,
-                          long long stride_z, int ncols, double* d_vt, GemmDesc* d_descs, int off) {
+                          long long stride_z, int ncols, double* d_vt, GemmDesc* d_descs, int off, int phase) {
+  // phase: 0 everything (on ctx->stream); or in three calls, so that the part that neither needs Z nor the scratch the
+  // D&C also uses can run on a second stream beside the D&C: 1 = descriptor upload, 2 = clean V, Gram products, T factors
+  // (launched on whatever ctx->stream is at the call), 3 = V T and the block applications
   hipStream_t st = ctx->stream;
   const int nref = n - 1 - off;  // reflector columns 0 .. nref-1 (a reflector needs two rows)
   if (nref <= 0) return SC_OK;
@@ -217,8 +220,10 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       h[5 * grp + (size_t)p * batch + b] = Y;
     }
   }
-  SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
+  if (phase == 0 || phase == 1) SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
+  if (phase == 1) return SC_OK;
 
+  if (phase == 0 || phase == 2) {
   hipLaunchKernelGGL(k_bt_clean, dim3((unsigned)npanels, (unsigned)batch), dim3(256), 0, st, d_a, stride_a, n, nbt,
                      nref, off);
   SC_TRY(launch_gemm_f64(ctx, d_descs, (int)grp, nbt, nbt, kGemmTile, BL.splits_g, false, false, kGemmAkBk));
@@ -226,6 +231,11 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
                      sizeof(double) * (kNbtT * kNbtT + kNbtT), st, d_tri_ws, TL, d_bt_ws, BL, nref);
   SC_TRY(launch_gemm_f64(ctx, d_descs + 4 * grp, (int)grp, kNbtT, kNbtT, kGemmTile, 1, false, false, kGemmAmBk));
   SC_TRY(launch_gemm_f64(ctx, d_descs + 5 * grp, (int)grp, kNbtT, kNbtT, kGemmTile, 1, false, false, kGemmAmBk));
+  }
+  if (phase == 2) {
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+  }
   SC_TRY(launch_gemm_f64(ctx, d_descs + grp, (int)grp, n, nbt, kGemmTile, 1, false, false, kGemmAmBk));
 
   PhaseTimer t_w(ctx, "bt1_w", st), t_u(ctx, "bt1_update", st);

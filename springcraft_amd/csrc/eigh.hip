@@ -233,36 +233,58 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
   } else {
     static const bool no_aux = getenv("SPRINGCRAFT_NO_AUX") != nullptr;
+    double* dc_ws = (double*)(base + P.off_dc);
+    double* bt_ws = (double*)(base + P.off_bt);
+    double* q_tmp = (double*)(base + P.off_qtmp);
+    double* u = (double*)(base + P.off_u);
+    GemmDesc* bt_descs = descs + P.n_syr2k + P.n_merge;
+    const int bt_off = P.two ? sb_band_width() : 1;
     if (P.two && no_aux) {
       t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", st));
       t_tf->start();
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, st));
       t_tf->stop();
-    } else if (P.two) {
-      // the diamonds' T factors do not depend on the tridiagonal eigenproblem: second stream, alongside the D&C
+    } else if (!no_aux) {
+      // what the back-transformations need besides Z does not depend on the tridiagonal eigenproblem: the diamonds' T
+      // factors (two-stage) and the cleaned reflectors, Gram products and T factors of the Q1 blocks run on a second
+      // stream alongside the D&C (their descriptors are uploaded on the main stream before the fork)
+      SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
+                                   bt_descs, bt_off, /*phase=*/1));
       SC_TRY(sc_aux_stream(ctx));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
       SC_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
-      t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", ctx->aux_stream));
-      t_tf->start();
-      SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, ctx->aux_stream));
-      t_tf->stop();
-      SC_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+      if (P.two) {
+        t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", ctx->aux_stream));
+        t_tf->start();
+        SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, ctx->aux_stream));
+        t_tf->stop();
+      }
+      {
+        ctx->stream = ctx->aux_stream;   // (launch_gemm_f64 launches on the context's stream)
+        const int rc_prep = backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a,
+                                                  n, q_tmp, bt_descs, bt_off, /*phase=*/2);
+        ctx->stream = st;
+        SC_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+        if (rc_prep != SC_OK) {
+          SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+          return rc_prep;
+        }
+      }
     }
-    double* dc_ws = (double*)(base + P.off_dc);
-    double* bt_ws = (double*)(base + P.off_bt);
-    double* q_tmp = (double*)(base + P.off_qtmp);
-    double* u = (double*)(base + P.off_u);
-    SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
-                         descs + P.n_syr2k));
+    {
+      const int rc_dc = stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
+                                      descs + P.n_syr2k);
+      if (rc_dc != SC_OK) {   // (the second stream is joined before an error leaves the solve)
+        if (!no_aux) (void)hipStreamWaitEvent(st, ctx->aux_join, 0);
+        return rc_dc;
+      }
+    }
     SC_TRY(unscale_values_batched(ctx, d_w, n, n, batch, tri_ws, P.TL));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    if (P.two) {
-      if (!no_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
-      SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
-    }
+    if (!no_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+    if (P.two) SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
-                                 descs + P.n_syr2k + P.n_merge, P.two ? sb_band_width() : 1));
+                                 bt_descs, bt_off, /*phase=*/no_aux ? 0 : 3));
   }
   if (prof) {
     SC_HIP(ctx, hipEventRecord(ev[3], st));

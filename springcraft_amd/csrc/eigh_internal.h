@@ -100,7 +100,7 @@ int bt_desc_count(int n, int batch);
 int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch,
                           const double* d_tri_ws, const TriLayout& TL, double* d_bt_ws,
                           const BtLayout& BL, double* d_z, long long stride_z, int ncols, double* d_vt,
-                          GemmDesc* d_descs /* bt_desc_count(n, batch) records */, int off = 1);
+                          GemmDesc* d_descs /* bt_desc_count(n, batch) records */, int off = 1, int phase = 0);
 
 // ---- two-stage tridiagonalisation (twostage.hip) ----------------------------------------------------------------
 struct SbLayout {
