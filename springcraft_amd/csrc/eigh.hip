@@ -239,12 +239,14 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
     double* u = (double*)(base + P.off_u);
     GemmDesc* bt_descs = descs + P.n_syr2k + P.n_merge;
     const int bt_off = P.two ? sb_band_width() : 1;
+    // (one structure on the one-stage path: the fork / join costs more than the overlap brings, 30.0 -> 31.3 ms at N = 512)
+    const bool use_aux = !no_aux && (P.two || batch >= 4);
     if (P.two && no_aux) {
       t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", st));
       t_tf->start();
       SC_TRY(bt2_prepare(ctx, n, batch, sb_ws, P.SL, st));
       t_tf->stop();
-    } else if (!no_aux) {
+    } else if (use_aux) {
       // what the back-transformations need besides Z does not depend on the tridiagonal eigenproblem: the diamonds' T
       // factors (two-stage) and the cleaned reflectors, Gram products and T factors of the Q1 blocks run on a second
       // stream alongside the D&C (their descriptors are uploaded on the main stream before the fork)
@@ -275,16 +277,16 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
       const int rc_dc = stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
                                       descs + P.n_syr2k);
       if (rc_dc != SC_OK) {   // (the second stream is joined before an error leaves the solve)
-        if (!no_aux) (void)hipStreamWaitEvent(st, ctx->aux_join, 0);
+        if (use_aux) (void)hipStreamWaitEvent(st, ctx->aux_join, 0);
         return rc_dc;
       }
     }
     SC_TRY(unscale_values_batched(ctx, d_w, n, n, batch, tri_ws, P.TL));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    if (!no_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+    if (use_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
     if (P.two) SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
-                                 bt_descs, bt_off, /*phase=*/no_aux ? 0 : 3));
+                                 bt_descs, bt_off, /*phase=*/use_aux ? 3 : 0));
   }
   if (prof) {
     SC_HIP(ctx, hipEventRecord(ev[3], st));
