@@ -1158,13 +1158,19 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         double* vn = vbuf[k & 1];
         // ---- wait for sweep s - 1
         if (tid == 0) {
-          int go = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
-          if (go && s > 0) {
-            const int need = min(k + 2, len_prev);
+          // (the stop flag and the predecessor's progress are requested TOGETHER: one L2 round trip, ~0.7 us, per task on
+          // the sweep-to-sweep critical path instead of two; while waiting, the flag is looked at every 16th poll only)
+          const int need = s > 0 ? min(k + 2, len_prev) : 0;
+          const int stop0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int have = s > 0 ? __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          int go = stop0 ? 0 : 1;
+          if (go) {
             long spins = 0;
-            while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            while (have < need) {
               // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
-              if (++spins > (1L << 21) || __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              ++spins;
+              if (spins > (1L << 21) ||
+                  ((spins & 15) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                   ctl[10] = b; ctl[11] = s; ctl[12] = k;
                 }
@@ -1172,7 +1178,8 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
                 go = 0;
                 break;
               }
-              __builtin_amdgcn_s_sleep(2);
+              __builtin_amdgcn_s_sleep(1);
+              have = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
           s_go = go;
