@@ -129,6 +129,50 @@ def host_threads():
         return int(os.cpu_count() or 1)
 
 
+# the CPU set this process was started with, recorded before bind_rank_to_numa_node narrows it
+_START_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+
+class host_cores:
+    """
+    Context of the CPU legs (cpu_baseline*, parity gates): SURVEY.md section 8(d) asks for the oracle "on the same box's
+    host cores", whatever launched this rank.  Two things stand in the way under ``torch.distributed.run``: the launcher
+    exports OMP_NUM_THREADS=1 when it is unset and there is more than one rank (OpenBLAS then runs numpy.linalg.eigh on
+    ONE thread), and bind_rank_to_numa_node has shrunk the affinity mask to one NUMA node for the GPU-driving phase.
+    Inside the context the mask the process started with is back and the BLAS / OpenMP pools are sized to it
+    (threadpoolctl sets them at run time, the environment variable is only their start-up default); both are
+    restored on exit.
+    """
+
+    def __enter__(self):
+        self.saved_affinity = None
+        self.limits = None
+        if _START_AFFINITY is not None:
+            try:
+                self.saved_affinity = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, _START_AFFINITY)
+            except OSError:
+                self.saved_affinity = None
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(os.cpu_count() or 1)
+        try:
+            from threadpoolctl import threadpool_limits
+
+            self.limits = threadpool_limits(limits=ncores)
+        except Exception:   # noqa: BLE001  (no threadpoolctl: the pools keep their start-up size, `cores` reports it)
+            self.limits = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.limits is not None:
+            self.limits.restore_original_limits()
+        if self.saved_affinity is not None:
+            try:
+                os.sched_setaffinity(0, self.saved_affinity)
+            except OSError:
+                pass
+        return False
+
+
 def cpu_baseline(n_atoms, ff_name, runs=3, budget_s=12.0):
     """
     Oracle on the host cores: ONE structure of the same workload per run, at least `runs` runs and as many more as fit
@@ -194,21 +238,36 @@ def cpu_baseline_partial(n_atoms, n_modes, sample_atoms=3000):
     }
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def spawn_ranks(args):
     """
     --gpus N without a rank environment: start the N ranks as a child job (nothing here has touched the GPU).  Every rank
     binds itself to the host cores next to its GPU before its first GPU call (bind_rank_to_numa_node).
     """
-    import socket
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=spawn_env(args.gpus))
+
+
+def spawn_env(nproc):
+    """
+    Environment of the rank processes.  torch.distributed.run sets OMP_NUM_THREADS=1 for every rank when the variable is
+    unset and nproc > 1; give it explicitly instead: the cores this process may use, shared out over the ranks (the CPU
+    baseline leg of rank 0 widens its pools to all of them at run time, see host_cores).
+    """
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(os.cpu_count() or 1)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, ncores // max(1, nproc))))
+    return env
 
 
 def bind_rank_to_numa_node(local_rank):
@@ -516,12 +575,13 @@ def run_batch(args, rank, world, torch, dist):
         value = nmodes * total_structures / elapsed
         cpu = gates = None
         if not args.no_cpu_baseline:
-            if subset is None:
-                cpu, cpu_h, cpu_pairs, cpu_w = cpu_baseline(n_atoms, ff_name, runs=args.cpu_runs)
-                gates = parity_gates(sc, solver, coord, w, v, n_atoms, ff_name, cpu_h, cpu_pairs, cpu_w, torch)
-            else:
-                gates = parity_gates_partial(solver, coord, w.clone(), v.clone(), torch)
-                cpu = cpu_baseline_partial(n_atoms, nmodes)
+            with host_cores():
+                if subset is None:
+                    cpu, cpu_h, cpu_pairs, cpu_w = cpu_baseline(n_atoms, ff_name, runs=args.cpu_runs)
+                    gates = parity_gates(sc, solver, coord, w, v, n_atoms, ff_name, cpu_h, cpu_pairs, cpu_w, torch)
+                else:
+                    gates = parity_gates_partial(solver, coord, w.clone(), v.clone(), torch)
+                    cpu = cpu_baseline_partial(n_atoms, nmodes)
         out = {
             "metric": metric,
             "value": round(value, 1), "unit": "modes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -599,7 +659,8 @@ def run_c4(args, rank, world, torch, dist):
         if not args.no_cpu_baseline:
             from oracle import enm_oracle as orc
 
-            cpu, _, _, cpu_w = cpu_baseline(n_atoms, "inv13", runs=args.cpu_runs)
+            with host_cores():
+                cpu, _, _, cpu_w = cpu_baseline(n_atoms, "inv13", runs=args.cpu_runs)
             w0 = w[0]
             gates = {
                 "eigenvalues_max_rel_diff_nontrivial": float((np.abs(w0[6:] - cpu_w[6:]) / np.abs(cpu_w[6:])).max()),
@@ -608,8 +669,9 @@ def run_c4(args, rank, world, torch, dist):
                 "orthogonality_max_all_ranks": float(worst[1]),
             }
             # the gathered eigenvalues of the LAST structure come from the last rank: check them against the oracle too
-            hl, _ = orc.compute_hessian(coords[-1], orc.invariant_ff(13.0))
-            wl = np.linalg.eigvalsh(hl)
+            with host_cores():
+                hl, _ = orc.compute_hessian(coords[-1], orc.invariant_ff(13.0))
+                wl = np.linalg.eigvalsh(hl)
             gates["last_structure_eigenvalues_max_rel_diff"] = float((np.abs(w[-1][6:] - wl[6:]) / np.abs(wl[6:])).max())
             gates["pass"] = bool(gates["eigenvalues_max_rel_diff_nontrivial"] <= 1e-5
                                  and gates["last_structure_eigenvalues_max_rel_diff"] <= 1e-5
@@ -681,7 +743,10 @@ def main():
     torch.cuda.set_device(dev_index)
     if world > 1 or args.config == "c4":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT (start the ranks with torch.distributed.run)")
+            os.environ["MASTER_PORT"] = str(free_port())   # single-process group of --config c4: any free port will do
         if share and world > ndev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -222,6 +222,26 @@ int sc_batch_plan_create(sc_ctx* ctx, int dim, const sc_structure_desc* structur
  * d_matrix: (count, order, order) f64.  Enqueued on the context's stream, nothing synchronises. */
 int sc_batch_plan_assemble_f64(sc_batch_plan* plan, const double* d_coord, const double* d_inv_sqrt_mass,
                                double* d_matrix);
+/* Host-callback force fields for a whole batch: any Python ForceField.force_constant (forcefield.py:67-94; the use
+ * doc/advanced.rst:23-70 documents and tests/test_interaction.py:92-116 exercises), which compute_kirchhoff /
+ * compute_hessian evaluate on the ordered pair list (interaction.py:49,96).  The plan's descriptors then only drive
+ * the contact scan (cutoff + adjacency patches, interaction.py:149-178):
+ *   1. sc_batch_plan_contacts: n_pairs[count] (host) = directed contacts per structure;
+ *   2. sc_batch_plan_pairs: pair lists of ALL structures in one launch, back to back -- per structure in np.where order
+ *      (sorted by i then j, both directions, interaction.py:177-178), LOCAL atom indices; pair_off[count + 1] (host) =
+ *      first row of every structure; sq_dist (may be NULL) as in sc_pairs; `capacity` rows were allocated;
+ *   3. the caller evaluates gamma[k] per structure;
+ *   4. sc_batch_plan_fill_from_pairs_f64: all padded slots from pairs + gamma in one pass over the batch.  Asymmetric
+ *      gamma is honoured as the reference does: element (i, j) from gamma(i, j), diagonal (blocks) = minus the sums
+ *      over the FIRST index (interaction.py:50-52,103-104); d_inv_sqrt_mass as in sc_batch_plan_assemble_f64.
+ * pairs / sq_dist / gamma / pair_off / n_pairs are HOST pointers, d_coord / d_matrix device pointers; all three calls
+ * synchronise the context's stream (the constants come from the host in between anyway). */
+int sc_batch_plan_contacts(sc_batch_plan* plan, const double* d_coord, int64_t* n_pairs);
+int sc_batch_plan_pairs(sc_batch_plan* plan, const double* d_coord, int64_t capacity, int64_t* pairs, double* sq_dist,
+                        int64_t* pair_off);
+int sc_batch_plan_fill_from_pairs_f64(sc_batch_plan* plan, const double* d_coord, const int64_t* pairs,
+                                      const int64_t* pair_off, const double* gamma, const double* d_inv_sqrt_mass,
+                                      double* d_matrix);
 int64_t sc_batch_plan_order(const sc_batch_plan* plan);
 /* Must be destroyed before its context. */
 void sc_batch_plan_destroy(sc_batch_plan* plan);

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "sc_modes_from_coord", "sc_modes_from_matrix", "sc_modes_destroy", "sc_modes_order", "sc_modes_get",
     "sc_modes_msf", "sc_modes_dcc", "sc_modes_prs", "sc_ctx_set_two_stage", "sc_last_eigh_phase_ms",
     "sc_ctx_get_counter", "sc_batch_plan_create", "sc_batch_plan_assemble_f64", "sc_batch_plan_order",
-    "sc_batch_plan_destroy",
+    "sc_batch_plan_destroy", "sc_batch_plan_contacts", "sc_batch_plan_pairs", "sc_batch_plan_fill_from_pairs_f64",
 ]
 
 
@@ -175,6 +175,9 @@ def lib():
         "sc_ctx_get_counter": (i32, [vp, C.c_char_p, P(i64)]),
         "sc_batch_plan_create": (i32, [vp, i32, P(StructureDesc), i64, i64, P(vp)]),
         "sc_batch_plan_assemble_f64": (i32, [vp, vp, vp, vp]),
+        "sc_batch_plan_contacts": (i32, [vp, vp, vp]),
+        "sc_batch_plan_pairs": (i32, [vp, vp, i64, vp, vp, vp]),
+        "sc_batch_plan_fill_from_pairs_f64": (i32, [vp, vp, vp, vp, vp, vp, vp]),
         "sc_batch_plan_order": (i64, [vp]),
         "sc_batch_plan_destroy": (None, [vp]),
         "sc_modes_from_coord": (i32, [vp, vp, i64, i32, P(FFDesc), P(PatchDesc), vp, P(vp)]),
@@ -254,7 +257,18 @@ class Context:
         return buf.value.decode()
 
     def close(self):
+        """
+        Destroys the context.  A deferred solver status nobody asked for (``synchronize`` / a solver's ``finish``) would
+        be lost with it -- the reference would have raised LinAlgError at nma.py:61 -- so it is turned into a warning.
+        """
         if self._h is not None and self._h.value:
+            rc = self._L.sc_ctx_synchronize(self._h)
+            if rc == SC_ERR_NOCONV:
+                import warnings
+
+                msg = self._L.sc_last_error(self._h)
+                warnings.warn("springcraft_amd context closed with an unreported solver failure: "
+                              + (msg.decode() if msg else "Eigenvalues did not converge"), RuntimeWarning, stacklevel=2)
             self._L.sc_ctx_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -114,9 +114,22 @@ class DeviceBatchSolver:
         return self.w, self.v
 
     def solve(self, coord):
-        """One pass of the hot path over the batch: assembly + eigensolve, all on device."""
+        """
+        One pass of the hot path over the batch: assembly + eigensolve, all on device.  Only ENQUEUES (the result tensors
+        are valid in stream order); call :meth:`finish` before trusting them on the host.
+        """
         self.assemble(coord)
         return self.eigh()
+
+    def finish(self):
+        """
+        Wait for the solves enqueued so far and raise what they could only find out on the device:
+        ``np.linalg.LinAlgError`` -- what ``np.linalg.eigh`` raises at nma.py:61 -- if a matrix held a NaN / Inf entry
+        (its eigenvalues come back NaN, the other structures of the batch are unaffected) or a tridiagonal QL iteration
+        did not converge.  The condition is reported once.  Returns (w, v).
+        """
+        self.ctx.synchronize()
+        return self.w, self.v
 
 
 class RaggedBatchSolver:
@@ -126,6 +139,12 @@ class RaggedBatchSolver:
     those included -- and in their masses (anm.py:89-94).  The reference models one arbitrary structure per object
     (anm.py:62-63); here every structure gets a slot of one common matrix order in a single batched eigensolve
     (``sc_batch_plan_*`` in the C ABI, which documents the exact padding of the slots).
+
+    User-defined :class:`ForceField` subclasses (``force_constant()`` in Python: doc/advanced.rst:23-70,
+    tests/test_interaction.py:92-116) are batched too: as soon as one member needs the host callback, the pair lists of
+    ALL structures come back from one device launch (``sc_batch_plan_pairs``), every structure's force field evaluates
+    its constants on its own ordered pairs exactly as interaction.py:49 / :96 do, and one device pass fills all padded
+    slots (``sc_batch_plan_fill_from_pairs_f64``; asymmetric constants honoured as interaction.py:50-52,103-104).
 
     sizes         atom counts, one per structure
     force_fields  one force field for all structures (only if it is not bound to particular atoms) or one per structure
@@ -156,17 +175,21 @@ class RaggedBatchSolver:
         self._keep = []          # descriptor memory must outlive sc_batch_plan_create
         descs = (_hip.StructureDesc * self.batch)()
         plans = {}
+        self.force_fields = list(force_fields)
+        self.host_callback = False       # True: gamma comes from force_constant() in Python for the whole batch
         for b, (n, ff) in enumerate(zip(self.sizes, force_fields)):
             if ff.natoms is not None and ff.natoms != n:
                 raise ValueError(f"structure {b}: the force field was built for {ff.natoms} atoms, the structure has {n}")
             if id(ff) not in plans:
                 ff_desc, patch, fused = device_plan(ff)
                 if not fused:
-                    raise ValueError(f"structure {b}: {type(ff).__name__} needs the host-callback path "
-                                     "(force_constant() in Python), which has no batched form")
+                    self.host_callback = True
                 pd = None
                 if patch is not None:
-                    pd = _hip.make_patch_desc(patch[0], patch[1], patch[2], patch[3], patch[4], self._keep)
+                    from .interaction import _normalised_patch
+
+                    # (negative indices, boolean masks, IndexError / self-pair ValueError as compute_* raise them)
+                    pd = _normalised_patch(patch, n, self._keep)
                 plans[id(ff)] = (ff_desc, pd)
                 self._keep += [ff_desc, pd, ff]
             ff_desc, pd = plans[id(ff)]
@@ -211,8 +234,40 @@ class RaggedBatchSolver:
         assert coord.is_cuda and coord.dtype == self.torch.float64 and coord.is_contiguous()
         assert tuple(coord.shape) == (int(self.offsets[-1]), 3)
         wp = C.c_void_p(self.inv_sqrt_mass.data_ptr()) if self.inv_sqrt_mass is not None else None
+        if self.host_callback:
+            return self._assemble_from_pairs(coord, wp)
         self.ctx.check(self._L.sc_batch_plan_assemble_f64(self._plan, C.c_void_p(coord.data_ptr()), wp,
                                                           C.c_void_p(self.matrix.data_ptr())))
+        return self.matrix
+
+    def pairs(self, coord, want_sq_dist=True):
+        """
+        Ordered pair lists of all structures from ONE device launch: [(pairs_b (k_b, 2) int64, sq_dist_b (k_b,)), ...],
+        per structure what ``compute_kirchhoff`` / ``compute_hessian`` return as ``pairs`` (interaction.py:177-178).
+        """
+        self.torch.cuda.current_stream(self.device).synchronize()     # coord may come from torch's stream
+        cp = C.c_void_p(coord.data_ptr())
+        counts = np.zeros(self.batch, dtype=np.int64)
+        self.ctx.check(self._L.sc_batch_plan_contacts(self._plan, cp, _hip.ptr(counts)))
+        k = int(counts.sum())
+        pairs = np.empty((k, 2), dtype=np.int64)
+        sq = np.empty(k, dtype=np.float64) if want_sq_dist else None
+        off = np.zeros(self.batch + 1, dtype=np.int64)
+        self.ctx.check(self._L.sc_batch_plan_pairs(self._plan, cp, k, _hip.ptr(pairs), _hip.ptr(sq), _hip.ptr(off)))
+        self._pairs_flat, self._pair_off = pairs, off
+        return [(pairs[off[b]: off[b + 1]], sq[off[b]: off[b + 1]] if sq is not None else None) for b in range(self.batch)]
+
+    def _assemble_from_pairs(self, coord, wp):
+        per = self.pairs(coord, want_sq_dist=True)
+        gamma = np.empty(len(self._pairs_flat), dtype=np.float64)
+        for b, ((pb, sqb), ff) in enumerate(zip(per, self.force_fields)):
+            g = np.asarray(ff.force_constant(pb[:, 0], pb[:, 1], sqb))   # interaction.py:49,96
+            if g.shape != (len(pb),):
+                raise ValueError(f"structure {b}: force_constant() returned shape {g.shape} for {len(pb)} pairs")
+            gamma[self._pair_off[b]: self._pair_off[b + 1]] = g          # (Tabulated returns float32: promoted here)
+        self.ctx.check(self._L.sc_batch_plan_fill_from_pairs_f64(
+            self._plan, C.c_void_p(coord.data_ptr()), _hip.ptr(self._pairs_flat), _hip.ptr(self._pair_off),
+            _hip.ptr(gamma), wp, C.c_void_p(self.matrix.data_ptr())))
         return self.matrix
 
     def eigh(self):
@@ -225,8 +280,17 @@ class RaggedBatchSolver:
         self.assemble(coord)
         return self.eigh()
 
+    def finish(self):
+        """As :meth:`DeviceBatchSolver.finish`: wait, and raise ``np.linalg.LinAlgError`` for NaN / Inf input or a QL failure."""
+        self.ctx.synchronize()
+        return self.w, self.v
+
     def results(self):
-        """Per-structure views of the last solve: [(w_i, v_i or None), ...]."""
+        """
+        Per-structure views of the last solve: [(w_i, v_i or None), ...].  Waits for the solve and raises
+        ``np.linalg.LinAlgError`` as ``np.linalg.eigh`` does at nma.py:61 (see :meth:`finish`).
+        """
+        self.ctx.synchronize()
         out = []
         for b, n in enumerate(self.sizes):
             m = self.dim * n
@@ -291,6 +355,9 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
     other ranks returns that rank's local results.
 
     Exchange steps (the only communication): scatter of coordinate shards, gather of eigenvalues.
+    A solve that fails on the device (NaN / Inf in a matrix, QL iteration without convergence) raises
+    ``np.linalg.LinAlgError`` -- what ``np.linalg.eigh`` raises at nma.py:61 -- on the rank it happened on AND on the
+    root, both after the gather (the flag travels with the eigenvalues, so no rank is left waiting in a collective).
     ``solver_factory(n_atoms, batch)`` may replace the device solver (used by the CPU/gloo tests,
     which check the sharding and the collectives, not the arithmetic).  ``solver``: a
     :class:`DeviceBatchSolver` built for this rank's shard size, reused across calls (its buffers and
@@ -336,8 +403,10 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
     # ---- local solve ----------------------------------------------------------------------------------
     nloc = hi - lo
     m = n_atoms * dim
-    w_local = torch.zeros((max_local, m), dtype=torch.float64, device=dev)
+    # (row max_local of the gathered buffer carries the rank's deferred solver status: 0 = fine)
+    w_local = torch.zeros((max_local + 1, m), dtype=torch.float64, device=dev)
     v_local = None
+    failure = None
     if nloc > 0:
         if solver_factory is None:
             if solver is None:
@@ -347,22 +416,43 @@ def solve_sharded(coords, force_field, dim=3, want_vectors=False, group=None, so
                                  f"this rank's shard is {(n_atoms, nloc, dim)}")
             # (with a CPU backend such as gloo the shards travel as CPU tensors: onto the solver's GPU and back)
             w, v_local = solver.solve(local[:nloc].to(solver.device).contiguous())
+            try:
+                solver.finish()
+            except np.linalg.LinAlgError as e:     # keep the collectives matched: report after the gather
+                failure = e
             w_local[:nloc] = w.to(dev)
         else:
-            w_np, v_local = solver_factory(n_atoms, nloc)(local[:nloc].cpu().numpy())
-            w_local[:nloc] = torch.from_numpy(np.asarray(w_np)).to(dev)
+            try:
+                w_np, v_local = solver_factory(n_atoms, nloc)(local[:nloc].cpu().numpy())
+                w_local[:nloc] = torch.from_numpy(np.asarray(w_np)).to(dev)
+            except np.linalg.LinAlgError as e:
+                failure = e
+                w_local[:nloc] = float("nan")
+    if failure is not None:
+        w_local[max_local, 0] = 1.0
 
     # ---- gather eigenvalues on the root -----------------------------------------------------------------
     if distributed:
         gathered = [torch.zeros_like(w_local) for _ in range(world)] if rank == 0 else None
         dist.gather(w_local, gathered, dst=0, group=group)
+        if failure is not None:
+            raise np.linalg.LinAlgError(f"rank {rank}: {failure}")
         if rank == 0:
             out = np.empty((n_items, m))
+            failed = []
             for r in range(world):
                 a, b = shard_bounds(n_items, world, r)
-                out[a:b] = gathered[r][: b - a].cpu().numpy()
+                g = gathered[r].cpu().numpy()
+                out[a:b] = g[: b - a]
+                if g[max_local, 0] != 0.0:
+                    failed.append(r)
+            if failed:
+                raise np.linalg.LinAlgError(f"Eigenvalues did not converge on rank(s) {failed} (NaN / Inf input or a "
+                                            "failed QL iteration; see that rank's exception)")
             return out, v_local
         return w_local[:nloc].cpu().numpy(), v_local
+    if failure is not None:
+        raise failure
     return w_local[:nloc].cpu().numpy(), v_local
 
 
@@ -390,11 +480,13 @@ def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=Non
 
     ``coords_list``: list of (N_i, 3) float64 arrays on the ROOT rank (rank 0); other ranks pass None.  The root
     broadcasts the sizes, every rank derives the same :func:`partition_lpt` with cost N_i^3, the root scatters one packed
-    (padded) coordinate buffer per rank, each rank solves its structures -- grouped by size, one
-    :class:`DeviceBatchSolver` batch per distinct N -- and the root gathers the packed eigenvalues.  Returns on rank 0
+    (padded) coordinate buffer per rank, each rank solves its structures -- ONE padded :class:`RaggedBatchSolver` batch
+    per bucket of similar sizes (:func:`size_buckets`: (N_max / N)^3 <= ``max_flop_ratio``, so no member pays more than
+    that factor for its padding) -- and the root gathers the packed eigenvalues.  Returns on rank 0
     the list of eigenvalue arrays in input order, on the other ranks a dict {item index: eigenvalues} of the local items.
     Two exchange steps, as in :func:`solve_sharded`; eigenvectors are not returned (they stay where they were computed,
-    inside the solvers' buffers).  ``solvers``: optional dict {(n_atoms, batch): DeviceBatchSolver} reused across calls.
+    inside the solvers' buffers).  ``solvers``: optional dict {tuple of the bucket's sizes: RaggedBatchSolver} reused
+    across calls.  Device-side failures raise ``np.linalg.LinAlgError`` after the gather, as in :func:`solve_sharded`.
     """
     import torch
     import torch.distributed as dist
@@ -453,13 +545,19 @@ def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=Non
     for i in mine:
         offsets[i] = off
         off += sizes[i]
-    w_local = torch.zeros(pad_atoms * dim, dtype=torch.float64, device=dev)
+    # (the last element of the gathered buffer carries the rank's deferred solver status: 0 = fine)
+    w_local = torch.zeros(pad_atoms * dim + 1, dtype=torch.float64, device=dev)
     results = {}
+    failure = None
     if solver_factory is not None:
         for n_atoms in sorted({sizes[i] for i in mine}):
             items = [i for i in mine if sizes[i] == n_atoms]
             batch = torch.stack([local[offsets[i]: offsets[i] + n_atoms] for i in items]).contiguous()
-            w_np, _ = solver_factory(n_atoms, len(items))(batch.cpu().numpy())
+            try:
+                w_np, _ = solver_factory(n_atoms, len(items))(batch.cpu().numpy())
+            except np.linalg.LinAlgError as e:
+                failure = e
+                w_np = np.full((len(items), n_atoms * dim), np.nan)
             w = torch.from_numpy(np.asarray(w_np))
             for k, i in enumerate(items):
                 w_local[offsets[i] * dim: (offsets[i] + n_atoms) * dim] = w[k].to(dev)
@@ -475,22 +573,39 @@ def solve_ragged(coords_list, force_field, dim=3, group=None, solver_factory=Non
                     solvers[key] = solver
             packed = torch.cat([local[offsets[i]: offsets[i] + sizes[i]] for i in items]).to(solver.device).contiguous()
             solver.solve(packed)
-            for i, (wi, _) in zip(items, solver.results()):
+            try:
+                per_structure = solver.results()       # waits, raises what the device found
+            except np.linalg.LinAlgError as e:         # keep the collectives matched: report after the gather
+                failure = e
+                per_structure = solver.results()
+            for i, (wi, _) in zip(items, per_structure):
                 w_local[offsets[i] * dim: (offsets[i] + sizes[i]) * dim] = wi.to(dev)
                 results[i] = wi.cpu().numpy().copy()
+    if failure is not None:
+        w_local[-1] = 1.0
 
     # ---- gather the packed eigenvalues ------------------------------------------------------------------------------
     if distributed:
         gathered = [torch.zeros_like(w_local) for _ in range(world)] if rank == 0 else None
         dist.gather(w_local, gathered, dst=0, group=group)
+        if failure is not None:
+            raise np.linalg.LinAlgError(f"rank {rank}: {failure}")
         if rank != 0:
             return results
         out = [None] * B
+        failed = []
         for r, part in enumerate(parts):
             off = 0
             buf = gathered[r].cpu().numpy()
+            if buf[-1] != 0.0:
+                failed.append(r)
             for i in part:
                 out[i] = buf[off * dim: (off + sizes[i]) * dim].copy()
                 off += sizes[i]
+        if failed:
+            raise np.linalg.LinAlgError(f"Eigenvalues did not converge on rank(s) {failed} (NaN / Inf input or a failed "
+                                        "QL iteration; see that rank's exception)")
         return out
+    if failure is not None:
+        raise failure
     return [results[i] for i in range(B)]

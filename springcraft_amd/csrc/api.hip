@@ -757,6 +757,7 @@ struct sc_batch_plan {
   bool any_patch = false, any_pad = false;
   char* d_blob = nullptr;
   size_t off_items = 0, off_bound = 0;
+  std::vector<int64_t> atom_off;   // count + 1: first atom of every structure in the packed buffers
 };
 
 namespace {
@@ -903,6 +904,8 @@ int sc_batch_plan_create(sc_ctx* ctx, int dim, const sc_structure_desc* structur
   plan->ctx = ctx; plan->dim = dim; plan->count = count; plan->order = order; plan->max_atoms = (int)max_atoms;
   plan->any_patch = any_patch; plan->any_pad = any_pad;
   plan->d_blob = d_blob; plan->off_items = off_items; plan->off_bound = off_bound;
+  plan->atom_off.assign((size_t)count + 1, 0);
+  for (int64_t b = 0; b < count; ++b) plan->atom_off[(size_t)b + 1] = plan->atom_off[(size_t)b] + structures[b].n_atoms;
   *out = plan;
   return SC_OK;
 }
@@ -916,6 +919,105 @@ int sc_batch_plan_assemble_f64(sc_batch_plan* plan, const double* d_coord, const
   return launch_assemble_items(ctx, plan->dim, plan->d_blob + plan->off_items, plan->count, plan->max_atoms,
                                plan->any_patch, plan->any_pad, d_coord, d_inv_sqrt_mass, d_matrix,
                                reinterpret_cast<unsigned long long*>(plan->d_blob + plan->off_bound));
+}
+
+// Contact scan of every structure: counts per atom + their exclusive scan in the context's scratch; the per-structure
+// offsets of the pair list (count + 1) come back to `pair_off`.  Leaves d_off (atoms + 1 entries) valid in scratch.
+static int plan_scan(sc_batch_plan* plan, const double* d_coord, size_t extra_bytes, Bump& bump, int64_t** d_off_out,
+                     std::vector<int64_t>& pair_off) {
+  sc_ctx* ctx = plan->ctx;
+  const int64_t atoms = plan->atom_off.back();
+  SC_TRY(sc_reserve_scratch(ctx, (size_t)(2 * atoms + 2) * 8 + extra_bytes + 4096));
+  bump = Bump{(char*)ctx->scratch};
+  int64_t* d_counts = bump.take<int64_t>((size_t)atoms);
+  int64_t* d_off = bump.take<int64_t>((size_t)atoms + 1);
+  SC_TRY(launch_items_counts(ctx, plan->d_blob + plan->off_items, plan->count, plan->max_atoms, plan->any_patch, d_coord,
+                             d_counts));
+  SC_TRY(launch_exclusive_scan_i64(ctx, d_counts, atoms, d_off));
+  std::vector<int64_t> off((size_t)atoms + 1);
+  SC_HIP(ctx, hipMemcpyAsync(off.data(), d_off, ((size_t)atoms + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pair_off.resize((size_t)plan->count + 1);
+  for (int64_t b = 0; b <= plan->count; ++b) pair_off[(size_t)b] = off[(size_t)plan->atom_off[(size_t)b]];
+  *d_off_out = d_off;
+  return SC_OK;
+}
+
+int sc_batch_plan_contacts(sc_batch_plan* plan, const double* d_coord, int64_t* n_pairs) {
+  if (!plan) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = plan->ctx;
+  if (!d_coord || !n_pairs) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  Bump bump{};
+  int64_t* d_off = nullptr;
+  std::vector<int64_t> pair_off;
+  SC_TRY(plan_scan(plan, d_coord, 0, bump, &d_off, pair_off));
+  for (int64_t b = 0; b < plan->count; ++b) n_pairs[b] = pair_off[(size_t)b + 1] - pair_off[(size_t)b];
+  return SC_OK;
+}
+
+int sc_batch_plan_pairs(sc_batch_plan* plan, const double* d_coord, int64_t capacity, int64_t* pairs, double* sq_dist,
+                        int64_t* pair_off) {
+  if (!plan) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = plan->ctx;
+  if (!d_coord || !pair_off || capacity < 0 || (capacity > 0 && !pairs))
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  Bump bump{};
+  int64_t* d_off = nullptr;
+  std::vector<int64_t> off;
+  SC_TRY(plan_scan(plan, d_coord, (size_t)capacity * 24 + 1024, bump, &d_off, off));
+  for (int64_t b = 0; b <= plan->count; ++b) pair_off[b] = off[(size_t)b];
+  const int64_t k = off.back();
+  if (k > capacity)
+    return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pair buffer too small: %lld > %lld", (long long)k, (long long)capacity);
+  if (k == 0) return SC_OK;
+  int64_t* d_pairs = bump.take<int64_t>((size_t)capacity * 2 + 2);
+  double* d_sq = sq_dist ? bump.take<double>((size_t)capacity + 1) : nullptr;
+  SC_TRY(launch_items_pair_fill(ctx, plan->d_blob + plan->off_items, plan->count, plan->max_atoms, plan->any_patch, d_coord,
+                                d_off, d_pairs, d_sq));
+  SC_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, (size_t)k * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (sq_dist) SC_HIP(ctx, hipMemcpyAsync(sq_dist, d_sq, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_batch_plan_fill_from_pairs_f64(sc_batch_plan* plan, const double* d_coord, const int64_t* pairs,
+                                      const int64_t* pair_off, const double* gamma, const double* d_inv_sqrt_mass,
+                                      double* d_matrix) {
+  if (!plan) return SC_ERR_INVALID_ARG;
+  sc_ctx* ctx = plan->ctx;
+  if (!d_coord || !pair_off || !d_matrix) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "bad arguments");
+  if (pair_off[0] != 0) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pair_off[0] must be 0");
+  for (int64_t b = 0; b < plan->count; ++b) {
+    if (pair_off[b + 1] < pair_off[b]) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pair_off must not decrease");
+    const int64_t nb = plan->atom_off[(size_t)b + 1] - plan->atom_off[(size_t)b];
+    if (pair_off[b + 1] > pair_off[b] && (!pairs || !gamma))
+      return sc_set_error(ctx, SC_ERR_INVALID_ARG, "pairs / gamma is NULL");
+    for (int64_t p = 2 * pair_off[b]; p < 2 * pair_off[b + 1]; ++p)
+      if (pairs[p] < 0 || pairs[p] >= nb)
+        return sc_set_error(ctx, SC_ERR_INDEX, "pair index %lld out of range for the %lld atoms of structure %lld",
+                            (long long)pairs[p], (long long)nb, (long long)b);
+  }
+  const int64_t k = pair_off[plan->count];
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  SC_TRY(sc_reserve_scratch(ctx, (size_t)k * 24 + ((size_t)plan->count + 1) * 8 + 4096));
+  Bump bump{(char*)ctx->scratch};
+  int64_t* d_poff = bump.take<int64_t>((size_t)plan->count + 1);
+  int64_t* d_pairs = bump.take<int64_t>((size_t)k * 2 + 2);
+  double* d_g = bump.take<double>((size_t)k + 1);
+  // (pageable host memory: the copies are staged by the runtime before the call returns)
+  SC_HIP(ctx, hipMemcpyAsync(d_poff, pair_off, ((size_t)plan->count + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (k > 0) {
+    SC_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, (size_t)k * 16, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_g, gamma, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
+  SC_TRY(launch_items_from_pairs(ctx, plan->dim, plan->d_blob + plan->off_items, plan->count, plan->max_atoms, plan->order,
+                                 plan->any_pad, d_coord, d_poff, k, d_pairs, d_g, d_inv_sqrt_mass, d_matrix,
+                                 reinterpret_cast<unsigned long long*>(plan->d_blob + plan->off_bound)));
+  // the scratch arena is reused by the next call: the kernels that read it must have run
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
 }
 
 int64_t sc_batch_plan_order(const sc_batch_plan* plan) { return plan ? plan->order : 0; }

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_kirchhoff(const double* __restrict__ co
     patch = it.patch;
     coord = coord_all + (size_t)it.atom_off * 3;
     w = w_all ? w_all + it.atom_off : nullptr;
-    K = k_all + b * ld * ld;
+    K = k_all ? k_all + b * ld * ld : nullptr;
+    counts = counts_all ? counts_all + it.atom_off : nullptr;   // contact counts of all structures back to back
   } else {
     coord = coord_all + b * (size_t)n * 3;
     w = w_all ? w_all + b * (size_t)n : nullptr;
@@ -351,12 +352,23 @@ __global__ __launch_bounds__(256) void k_hessian(const double* __restrict__ coor
 // ---- ordered pair list (np.where order) ------------------------------------------------------------------
 // One wave per atom i; 64 candidate columns per step; ballot + prefix popcount gives each contact its
 // rank inside the row, so pairs come out sorted by (i, j) without atomics.
-template <bool PATCH>
+// ITEMS: structure blockIdx.y of a batch plan; `offsets` then spans the atoms of ALL structures back to back (one
+// exclusive scan), so every structure's rows land behind those of the structure before it, with local atom indices.
+template <bool PATCH, bool ITEMS = false>
 __global__ __launch_bounds__(256) void k_pair_fill(const double* __restrict__ coord, int n, FFDev ff,
                                                    PatchDev patch,
                                                    const long long* __restrict__ offsets,
                                                    long long* __restrict__ pairs,
-                                                   double* __restrict__ sqd) {
+                                                   double* __restrict__ sqd,
+                                                   const AsmItem* __restrict__ items = nullptr) {
+  if (ITEMS) {
+    const AsmItem it = items[blockIdx.y];
+    n = it.n;
+    ff = it.ff;
+    patch = it.patch;
+    coord += (size_t)it.atom_off * 3;
+    offsets += it.atom_off;
+  }
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -438,6 +450,81 @@ __global__ void k_hessian_diag(int n, double* __restrict__ H) {
     s += H[((size_t)3 * jp + a) * n3 + c];
   }
   H[(3 * i + a) * n3 + c] = -s;
+}
+
+// ---- host-callback path for a whole batch plan: pairs of all structures back to back, gamma from the host ------------
+// Pair p belongs to the structure b with pair_off[b] <= p < pair_off[b + 1] (binary search; count + 1 offsets).
+__device__ __forceinline__ int item_of_pair(const long long* __restrict__ pair_off, int count, long long p) {
+  int lo = 0, hi = count;   // invariant: pair_off[lo] <= p < pair_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_items_scatter(const AsmItem* __restrict__ items, int count,
+                                                       const long long* __restrict__ pair_off,
+                                                       const long long* __restrict__ pairs,
+                                                       const double* __restrict__ gamma,
+                                                       const double* __restrict__ coord_all, double* __restrict__ m_all) {
+  const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (p >= pair_off[count]) return;
+  const int b = item_of_pair(pair_off, count, p);
+  const AsmItem it = items[b];
+  const size_t ld = (size_t)it.ld;
+  double* M = m_all + (size_t)b * ld * ld;
+  const long long i = pairs[2 * p], j = pairs[2 * p + 1];
+  if (DIM == 1) {
+    M[(size_t)i * ld + j] = -gamma[p];                         // interaction.py:50
+  } else {
+    const double* coord = coord_all + (size_t)it.atom_off * 3;
+    const double dx = coord[3 * j + 0] - coord[3 * i + 0];
+    const double dy = coord[3 * j + 1] - coord[3 * i + 1];
+    const double dz = coord[3 * j + 2] - coord[3 * i + 2];
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
+    const double tt = (-gamma[p]) / d2;                        // interaction.py:96-101
+    const double d[3] = {dx, dy, dz};
+    for (int a = 0; a < 3; ++a) {
+      const double ta = tt * d[a];
+      for (int c = 0; c < 3; ++c) M[(size_t)(3 * i + a) * ld + 3 * j + c] = ta * d[c];
+    }
+  }
+}
+
+// diagonal (blocks): minus the sums over the FIRST index, sequential as np.sum(axis=0) (interaction.py:52,103-104);
+// grid (ceil(DIM * DIM * max_atoms / 256), count)
+template <int DIM>
+__global__ __launch_bounds__(256) void k_items_diag(const AsmItem* __restrict__ items, double* __restrict__ m_all) {
+  const AsmItem it = items[blockIdx.y];
+  const size_t ld = (size_t)it.ld;
+  double* M = m_all + (size_t)blockIdx.y * ld * ld;
+  const size_t idx = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (idx >= (size_t)it.n * DIM * DIM) return;
+  const size_t c = idx / DIM;            // matrix column
+  const int a = (int)(idx % DIM);        // row inside the block
+  const size_t i = c / DIM;              // atom of the column
+  double s = 0.0;
+  for (int jp = 0; jp < it.n; ++jp) {
+    if (DIM == 3 && (size_t)jp == i) continue;   // the (i, i) block is still zero in the reference at this point
+    s += M[((size_t)DIM * jp + a) * ld + c];
+  }
+  M[((size_t)DIM * i + a) * ld + c] = -s;
+}
+
+// M *= outer(w, w) with w = repeat(1 / sqrt(m), DIM)  (anm.py:89-94,112-113; gnm.py:85-87,104-105)
+__global__ __launch_bounds__(256) void k_items_weight(const AsmItem* __restrict__ items, int dim,
+                                                      const double* __restrict__ w_all, double* __restrict__ m_all) {
+  const AsmItem it = items[blockIdx.y];
+  const size_t ld = (size_t)it.ld;
+  const size_t m = (size_t)dim * it.n;
+  double* M = m_all + (size_t)blockIdx.y * ld * ld;
+  const double* w = w_all + it.atom_off;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < m * m; idx += (size_t)gridDim.x * 256) {
+    const size_t r = idx / m, c = idx % m;
+    M[r * ld + c] *= w[r / dim] * w[c / dim];
+  }
 }
 
 // ---- padded slots of a ragged batch ----------------------------------------------------------------------------
@@ -664,6 +751,78 @@ int launch_assemble_items(sc_ctx* ctx, int dim, const void* d_items, int64_t cou
     else
       hipLaunchKernelGGL((k_hessian<TI, false, true>), grid, dim3(256), 0, st, d_coord, 0, ff0, p0, d_w, d_matrix, items);
   }
+  if (any_pad) {
+    SC_HIP(ctx, hipMemsetAsync(d_bound_bits, 0, sizeof(unsigned long long) * (size_t)count, st));
+    hipLaunchKernelGGL(k_slot_bound, dim3((unsigned)((dim * max_atoms + 3) / 4), (unsigned)count), dim3(256), 0, st,
+                       d_matrix, items, dim, d_bound_bits);
+    hipLaunchKernelGGL(k_pad_fill, dim3(64, (unsigned)count), dim3(256), 0, st, d_matrix, items, dim, d_bound_bits);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// Contact counts of every structure of a plan (counts of all atoms back to back), one launch.
+int launch_items_counts(sc_ctx* ctx, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                        const double* d_coord, int64_t* d_counts) {
+  if (count <= 0 || max_atoms <= 0) return SC_OK;
+  const AsmItem* items = reinterpret_cast<const AsmItem*>(d_items);
+  constexpr int TI = 4;
+  const dim3 grid((unsigned)((max_atoms + TI - 1) / TI), (unsigned)count);
+  const FFDev ff0{};
+  const PatchDev p0{};
+  if (any_patch)
+    hipLaunchKernelGGL((k_kirchhoff<TI, true, true>), grid, dim3(256), 0, ctx->stream, d_coord, 0, ff0, p0,
+                       (const double*)nullptr, (double*)nullptr, (long long*)d_counts, items);
+  else
+    hipLaunchKernelGGL((k_kirchhoff<TI, false, true>), grid, dim3(256), 0, ctx->stream, d_coord, 0, ff0, p0,
+                       (const double*)nullptr, (double*)nullptr, (long long*)d_counts, items);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// Ordered pair lists (np.where order, local atom indices) of every structure, back to back; d_offsets: exclusive scan of
+// the counts over all atoms.
+int launch_items_pair_fill(sc_ctx* ctx, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                           const double* d_coord, const int64_t* d_offsets, int64_t* d_pairs, double* d_sqdist) {
+  if (count <= 0 || max_atoms <= 0) return SC_OK;
+  const AsmItem* items = reinterpret_cast<const AsmItem*>(d_items);
+  const dim3 grid((unsigned)((max_atoms + 3) / 4), (unsigned)count);
+  const FFDev ff0{};
+  const PatchDev p0{};
+  if (any_patch)
+    hipLaunchKernelGGL((k_pair_fill<true, true>), grid, dim3(256), 0, ctx->stream, d_coord, 0, ff0, p0,
+                       (const long long*)d_offsets, (long long*)d_pairs, d_sqdist, items);
+  else
+    hipLaunchKernelGGL((k_pair_fill<false, true>), grid, dim3(256), 0, ctx->stream, d_coord, 0, ff0, p0,
+                       (const long long*)d_offsets, (long long*)d_pairs, d_sqdist, items);
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// All slots of a plan from explicit pair lists + gamma (the host-callback path of compute_kirchhoff / compute_hessian,
+// interaction.py:49-52 / :94-104, for a whole batch): zero, scatter, diagonal, mass weights, pads.
+int launch_items_from_pairs(sc_ctx* ctx, int dim, const void* d_items, int64_t count, int max_atoms, int64_t order,
+                            bool any_pad, const double* d_coord, const int64_t* d_pair_off, int64_t k_total,
+                            const int64_t* d_pairs, const double* d_gamma, const double* d_w, double* d_matrix,
+                            unsigned long long* d_bound_bits) {
+  if (count <= 0 || max_atoms <= 0) return SC_OK;
+  const AsmItem* items = reinterpret_cast<const AsmItem*>(d_items);
+  hipStream_t st = ctx->stream;
+  SC_HIP(ctx, hipMemsetAsync(d_matrix, 0, sizeof(double) * (size_t)count * order * order, st));
+  const dim3 gp((unsigned)((k_total + 255) / 256));
+  const dim3 gd((unsigned)(((size_t)dim * dim * max_atoms + 255) / 256), (unsigned)count);
+  if (dim == 1) {
+    if (k_total > 0)
+      hipLaunchKernelGGL((k_items_scatter<1>), gp, dim3(256), 0, st, items, (int)count, (const long long*)d_pair_off,
+                         (const long long*)d_pairs, d_gamma, d_coord, d_matrix);
+    hipLaunchKernelGGL((k_items_diag<1>), gd, dim3(256), 0, st, items, d_matrix);
+  } else {
+    if (k_total > 0)
+      hipLaunchKernelGGL((k_items_scatter<3>), gp, dim3(256), 0, st, items, (int)count, (const long long*)d_pair_off,
+                         (const long long*)d_pairs, d_gamma, d_coord, d_matrix);
+    hipLaunchKernelGGL((k_items_diag<3>), gd, dim3(256), 0, st, items, d_matrix);
+  }
+  if (d_w) hipLaunchKernelGGL(k_items_weight, dim3(256, (unsigned)count), dim3(256), 0, st, items, dim, d_w, d_matrix);
   if (any_pad) {
     SC_HIP(ctx, hipMemsetAsync(d_bound_bits, 0, sizeof(unsigned long long) * (size_t)count, st));
     hipLaunchKernelGGL(k_slot_bound, dim3((unsigned)((dim * max_atoms + 3) / 4), (unsigned)count), dim3(256), 0, st,

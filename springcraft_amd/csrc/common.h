@@ -190,6 +190,17 @@ void asm_item_fill(void* dst, long long atom_off, int n, int ld, const sc_ff_des
 int launch_assemble_items(sc_ctx* ctx, int dim, const void* d_items, int64_t count, int max_atoms, bool any_patch,
                           bool any_pad, const double* d_coord, const double* d_w, double* d_matrix,
                           unsigned long long* d_bound_bits);
+// Host-callback force fields for a whole plan (sc_batch_plan_contacts / _pairs / _fill_from_pairs_f64): contact counts of
+// all atoms back to back; ordered pair lists (local indices) behind the exclusive scan of those counts; all slots from
+// pairs + gamma.
+int launch_items_counts(sc_ctx* ctx, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                        const double* d_coord, int64_t* d_counts);
+int launch_items_pair_fill(sc_ctx* ctx, const void* d_items, int64_t count, int max_atoms, bool any_patch,
+                           const double* d_coord, const int64_t* d_offsets, int64_t* d_pairs, double* d_sqdist);
+int launch_items_from_pairs(sc_ctx* ctx, int dim, const void* d_items, int64_t count, int max_atoms, int64_t order,
+                            bool any_pad, const double* d_coord, const int64_t* d_pair_off, int64_t k_total,
+                            const int64_t* d_pairs, const double* d_gamma, const double* d_w, double* d_matrix,
+                            unsigned long long* d_bound_bits);
 // In-place transpose-free symmetric "row-major == column-major" note: the eigensolver reads the
 // LOWER triangle in column-major order, i.e. the UPPER triangle of the row-major matrix the
 // assembly writes; the matrices are symmetric so both views agree.

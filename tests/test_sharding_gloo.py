@@ -68,6 +68,73 @@ def test_solve_sharded_two_ranks(n_items):
         assert np.allclose(w[s], orc.eigen(h)[0], atol=1e-10)
 
 
+def _failing_worker(rank, world, port, queue):
+    import torch.distributed as dist
+
+    from oracle import enm_oracle as orc
+    from springcraft_amd.batch import solve_ragged, solve_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def factory(n_atoms, batch):
+        def run(coords):
+            ws = []
+            for c in coords:
+                h, _ = orc.compute_hessian(c, orc.hinsen_ff())      # no cutoff: a NaN coordinate reaches the matrix
+                if not np.isfinite(h).all():                        # what the device solver reports (LAPACK builds differ:
+                    raise np.linalg.LinAlgError("Eigenvalues did not converge")   # some raise at nma.py:61, some return NaN)
+                ws.append(orc.eigen(h)[0])
+            return np.array(ws), None
+        return run
+
+    seen = []
+    coords = None
+    if rank == 0:
+        coords = np.stack([orc.synthetic_coord(20, s, 12.0) for s in range(4)])
+        coords[3, 5, 1] = np.nan                                    # structure 3 is solved by rank 1
+    try:
+        solve_sharded(coords, None, dim=3, solver_factory=factory)
+        seen.append("sharded: no error")
+    except np.linalg.LinAlgError as e:
+        seen.append("sharded: " + str(e))
+    try:
+        solve_ragged(list(coords) if rank == 0 else None, None, dim=3, solver_factory=factory)
+        seen.append("ragged: no error")
+    except np.linalg.LinAlgError as e:
+        seen.append("ragged: " + str(e))
+    # both calls left the collectives matched: one more collective still works
+    dist.barrier()
+    queue.put((rank, seen))
+    dist.destroy_process_group()
+
+
+def test_device_side_failure_raises_linalgerror_on_root_and_owner_without_hanging():
+    """
+    np.linalg.eigh raises LinAlgError for non-finite input (nma.py:61).  In the sharded form the failing rank must not
+    skip the gather (the others would wait for ever): the flag travels with the eigenvalues, the owner and the root
+    raise after the exchange.
+    """
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0].startswith("sharded: Eigenvalues did not converge on rank(s) [1]")
+    assert got[1][0].startswith("sharded: rank 1:")
+    # (solve_ragged's LPT partition decides who owns the NaN structure: the root reports the owner's rank)
+    assert got[0][1].startswith("ragged: ") and "no error" not in got[0][1]
+    assert any("rank" in got[r][1] and "no error" not in got[r][1] for r in (0, 1))
+
+
 # ---- ragged batches: longest-processing-time partition by N^3 (SURVEY 8e) -------------------------------------------
 def test_partition_lpt_properties():
     from springcraft_amd.batch import partition_lpt
