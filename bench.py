@@ -409,7 +409,19 @@ def bulge_compulsory_bytes(n):
     return 8 * (65 * n + refl)
 
 
-def build_rooflines(t, n, B, ncols):
+CHASE_COUNTERS = ("chase_launches", "chase_pair_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")
+
+
+def chase_form(before, after):
+    """Which form of the bulge chase a solve took, from the context's counters before / after it."""
+    if after["chase_pair_launches"] > before["chase_pair_launches"]:
+        return "pair"
+    if after["chase_launches"] > before["chase_launches"]:
+        return "sweep_per_workgroup"
+    return "per_wavefront"
+
+
+def build_rooflines(t, n, B, ncols, form="per_wavefront"):
     """
     (dominant-kernel roofline, all rooflines) from the phase durations `t` of one profiled step.  n: matrix order,
     B: matrices per launch, ncols: eigenvector columns the back-transformations are applied to.
@@ -448,18 +460,21 @@ def build_rooflines(t, n, B, ncols):
         mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
              "stage-1 back-transformation, second product: n^2 ncols flops per matrix")
         if t.get("bulge_chasing_ms", 0) > 0:
-            bb = bulge_bytes(n) * B
+            # pair form: one block set is read (team A) and one written (team B) per PAIR of tasks -- half the bytes
+            bb = bulge_bytes(n) * B // (2 if form == "pair" else 1)
             cb = bulge_compulsory_bytes(n) * B
             ms = t["bulge_chasing_ms"]
             bw = bb / (ms * 1e-3) / 1e9
             cand["bulge_chasing"] = {
-                "kernel": "k_bulge_step / k_bulge_chase", "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS,
+                "kernel": {"pair": "k_bulge_pair", "sweep_per_workgroup": "k_bulge_chase"}.get(form, "k_bulge_step"),
+                "form": form, "bound": "hbm", "achieved": round(bw, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(bw / HBM_PEAK_GBS, 4), "ms": round(ms, 3),
                 "executed_bytes_per_step": bb, "compulsory_bytes_per_step": cb,
                 "compulsory_frac": round(cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "executed_over_compulsory": round(bb / cb, 1),
                 "what": "stage 2 (band -> tridiagonal).  `achieved` counts what the implementation moves (every task reads "
-                        "and writes its off-diagonal block and the lower triangle of its diagonal block); "
+                        "and writes its off-diagonal block and the lower triangle of its diagonal block; in the pair form "
+                        "one workgroup chases two sweeps through LDS: one read + one write per PAIR of tasks); "
                         "`compulsory_*` counts only the band in + the reflectors out, the bytes any schedule must move.  "
                         "Wall time of the stage (HIP events; parts of the batch run on separate streams, so per-kernel "
                         "durations in a rocprof summary overlap and add up to more)",
@@ -546,11 +561,13 @@ def run_batch(args, rank, world, torch, dist):
     if rank == 0:
         # ---- one extra profiled step: durations of the kernel groups (HIP events, solver's stream)
         solver.set_profiling(True)
+        c_before = {k: solver.ctx.counter(k) for k in CHASE_COUNTERS}
         w, v = solver.solve(coord)
         torch.cuda.synchronize()
         t = solver.last_timings()
         solver.set_profiling(False)
-        roofline, rooflines = build_rooflines(t, n, B, nmodes)
+        form = chase_form(c_before, {k: solver.ctx.counter(k) for k in CHASE_COUNTERS})
+        roofline, rooflines = build_rooflines(t, n, B, nmodes, form)
         # ---- assembly roofline: k_hessian alone (one launch per assemble), events on the same stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
@@ -569,7 +586,7 @@ def run_batch(args, rank, world, torch, dist):
             "algorithmic_bytes_per_launch": round(asm_bytes),
             "what": "72 B per ordered atom pair (9 N^2 f64 written once) + 24 N B read, per structure",
         }
-        counters = {k: solver.ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")}
+        counters = {k: solver.ctx.counter(k) for k in CHASE_COUNTERS}
 
         total_structures = B * world * args.steps
         value = nmodes * total_structures / elapsed
@@ -649,12 +666,14 @@ def run_c4(args, rank, world, torch, dist):
     if rank == 0:
         # one extra profiled local solve of rank 0's shard: kernel-group durations -> rooflines
         solver.set_profiling(True)
+        c_before = {k: solver.ctx.counter(k) for k in CHASE_COUNTERS}
         solver.solve(local)
         torch.cuda.synchronize()
         tt = solver.last_timings()
         solver.set_profiling(False)
-        roofline, rooflines = build_rooflines(tt, n, hi - lo, n)
-        counters = {k: solver.ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")}
+        form = chase_form(c_before, {k: solver.ctx.counter(k) for k in CHASE_COUNTERS})
+        roofline, rooflines = build_rooflines(tt, n, hi - lo, n, form)
+        counters = {k: solver.ctx.counter(k) for k in CHASE_COUNTERS}
         cpu = gates = None
         if not args.no_cpu_baseline:
             from oracle import enm_oracle as orc

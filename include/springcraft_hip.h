@@ -278,7 +278,9 @@ int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
 int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
 
 /* Event counters of the context since it was created (monitoring; nothing in the reference corresponds).  Names:
- *   "chase_launches"   persistent bulge chases started (two-stage path, latency-bound batches)
+ *   "chase_launches"   persistent bulge chases started (two-stage path): one launch for the whole stage
+ *   "chase_pair_launches"   of those, how many ran in the pair form (two sweeps per workgroup through LDS, the form for
+ *                      batches that are bound by memory traffic; smaller ones take one sweep per workgroup)
  *   "chase_timeouts"   of those, how many ran into the bound of an inter-workgroup wait -- expected to stay 0; the
  *                      solve is still finished correctly by the per-wavefront launches ("chase_resumed" counts every
  *                      such take-over, "chase_incomplete" a chase that ended without a flag but with sweeps left),

@@ -53,9 +53,14 @@ int sc_dbg_bt2_trace(unsigned long long* out);
  * otherwise): out6 = {cycles from task start until the off-diagonal block E is in LDS, until E is stored [both: tasks
  * with k > 0], until the diagonal block D is in LDS, until the end; tasks; tasks with k > 0}.  tools/bulge_stamps.py */
 int sc_dbg_bulge_stamps(unsigned long long* out6);
+/* The same for the pair form of the persistent chase (k_bulge_pair; library built with -DPAIR_STAMPS, else returns 1):
+ * out16[0..7] = cycles of thread 0 between the nine barriers of a step (wait, loads, E right update + reflector,
+ * column sums, E left update + D products, w, D update, store drain), [8] = steps, [9] = steps with both teams at work. */
+int sc_dbg_pair_stamps(unsigned long long* out16);
 
 /* Persistent bulge chase of this context: mode -1 = SPRINGCRAFT_BULGE_PERSISTENT or the size rule (default), 0 never,
- * 1 by size, 2 always.  give_up_after > 0: test hook, every workgroup of the chase raises the time-out flag after that
+ * 1 by size, 2 always (3: always and in the pair form k_bulge_pair, 4: always with one sweep per workgroup,
+ * k_bulge_chase; 2 picks the form by size like the default).  give_up_after > 0: test hook, every workgroup of the chase raises the time-out flag after that
  * many tasks, which forces the take-over by the per-wavefront launches (counted in "chase_resumed", not in
  * "chase_timeouts").  tests/test_two_stage_gpu.py */
 int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after);

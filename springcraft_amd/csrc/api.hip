@@ -396,6 +396,7 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
     tmax = std::max(tmax, ctx->chase_tickets[x]);
   }
   if (k == "chase_launches") *value = ctx->cnt_chase_launches;
+  else if (k == "chase_pair_launches") *value = ctx->cnt_pair_launches;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
   else if (k == "chase_incomplete") *value = ctx->cnt_chase_incomplete;
   else if (k == "chase_resumed") *value = ctx->cnt_chase_resumed;
@@ -412,7 +413,10 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
 
 // debugging entry point (include/springcraft_hip_debug.h)
 int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after) {
-  if (!ctx || mode < -1 || mode > 2 || give_up_after < 0) return SC_ERR_INVALID_ARG;
+  if (!ctx || mode < -1 || mode > 4 || give_up_after < 0) return SC_ERR_INVALID_ARG;
+  // 3 / 4: persistent always, in the pair form / with one sweep per workgroup (2: always, the form by size)
+  ctx->chase_form = mode == 3 ? 1 : (mode == 4 ? 0 : -1);
+  if (mode > 2) mode = 2;
   ctx->chase_mode = mode;
   ctx->chase_give_up = give_up_after;
   if (mode >= 0) ctx->chase_ok = -1;

@@ -59,9 +59,10 @@ struct sc_ctx {
   // entry sc_dbg_set_chase (-1: SPRINGCRAFT_BULGE_PERSISTENT or the size rule; 0 / 1 / 2 as that variable).
   int chase_ok = -1;
   int chase_mode = -1, chase_give_up = 0;
+  int chase_form = -1;   // debug entry: 1 = pair form, 0 = one sweep per workgroup, -1 = by size
   // event counters since the context was created (sc_ctx_get_counter)
   long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
-            cnt_chase_sweeps = 0, cnt_stepwise_chases = 0;
+            cnt_chase_sweeps = 0, cnt_stepwise_chases = 0, cnt_pair_launches = 0;
   int chase_tickets[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // workgroups per XCD of the most recent chase launch
   int chase_wait[3] = {-1, -1, -1};                  // (matrix, sweep, task) of the wait that timed out last
   bool profiling = false;

@@ -175,6 +175,23 @@ size_t eigh_workspace_bytes(int64_t n, int64_t batch, bool want_vectors) {
   return make_plan(nullptr, (int)n, (int)batch, want_vectors).total;
 }
 
+// Once work has been forked onto the context's second stream, EVERY way out of the solve must make the main stream wait
+// for it: the kernels queued there read and write d_a, the band workspace and the back-transformation workspace, which
+// the caller may reuse or free as soon as the call has returned, and the next solve on the context must be ordered
+// after them (the band reduction's side streams got the same guard in round 3).
+struct AuxJoinGuard {
+  sc_ctx* ctx;
+  hipStream_t main;
+  bool forked = false, joined = false;
+  ~AuxJoinGuard() {
+    ctx->stream = main;   // (a failing call between the two assignments below must not leave the context on the aux stream)
+    if (forked && !joined) {
+      (void)hipEventRecord(ctx->aux_join, ctx->aux_stream);
+      (void)hipStreamWaitEvent(main, ctx->aux_join, 0);
+    }
+  }
+};
+
 int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, double* d_w, double* d_v) {
   if (n64 > 46000) return sc_set_error(ctx, SC_ERR_INVALID_ARG, "matrix order %lld too large", (long long)n64);
   const int n = (int)n64, batch = (int)batch64;
@@ -241,6 +258,7 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
     const int bt_off = P.two ? sb_band_width() : 1;
     // (one structure on the one-stage path: the fork / join costs more than the overlap brings, 30.0 -> 31.3 ms at N = 512)
     const bool use_aux = !no_aux && (P.two || batch >= 4);
+    AuxJoinGuard aux{ctx, st};
     if (P.two && no_aux) {
       t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", st));
       t_tf->start();
@@ -255,6 +273,7 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
       SC_TRY(sc_aux_stream(ctx));
       SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
       SC_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+      aux.forked = true;
       if (P.two) {
         t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", ctx->aux_stream));
         t_tf->start();
@@ -266,24 +285,17 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
         const int rc_prep = backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a,
                                                   n, q_tmp, bt_descs, bt_off, /*phase=*/2);
         ctx->stream = st;
+        if (rc_prep != SC_OK) return rc_prep;     // (joined by the guard)
         SC_HIP(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
-        if (rc_prep != SC_OK) {
-          SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
-          return rc_prep;
-        }
       }
     }
-    {
-      const int rc_dc = stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a,
-                                      descs + P.n_syr2k);
-      if (rc_dc != SC_OK) {   // (the second stream is joined before an error leaves the solve)
-        if (use_aux) (void)hipStreamWaitEvent(st, ctx->aux_join, 0);
-        return rc_dc;
-      }
-    }
+    SC_TRY(stedc_batched(ctx, n, batch, tri_ws, P.TL, dc_ws, P.DL, d_w, n, d_v, q_tmp, u, stride_a, descs + P.n_syr2k));
     SC_TRY(unscale_values_batched(ctx, d_w, n, n, batch, tri_ws, P.TL));
     if (prof) SC_HIP(ctx, hipEventRecord(ev[2], st));
-    if (use_aux) SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+    if (use_aux) {
+      SC_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_join, 0));
+      aux.joined = true;
+    }
     if (P.two) SC_TRY(bt2_batched(ctx, n, batch, sb_ws, P.SL, (const int*)(base + P.off_dia), d_v, stride_a, n, &ms_bt2));
     SC_TRY(backtransform_batched(ctx, d_a, stride_a, n, batch, tri_ws, P.TL, bt_ws, P.BL, d_v, stride_a, n, q_tmp,
                                  bt_descs, bt_off, /*phase=*/use_aux ? 3 : 0));

@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_a
 constexpr int kChaseCtlInts = 32;
 
 
-__global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W,
+__global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W, int nxcd,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
                                                      int* __restrict__ ctl, int give_up_after) {
   constexpr int LD = kB + 1;
@@ -1120,19 +1120,19 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
   if (tid == 0) {
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-    s_xcd = (int)(id & 7u);
+    s_xcd = (int)(id & 7u) % nxcd;
     s_slot = atomicAdd(ctl + 2 + s_xcd, 1);
   }
   __syncthreads();
   const int xcd = s_xcd, slot = s_slot;
-  const int mpx = xcd < batch ? (batch - xcd + 7) / 8 : 0;   // matrices of this XCD: xcd, xcd + 8, ...
+  const int mpx = xcd < batch ? (batch - xcd + nxcd - 1) / nxcd : 0;   // matrices of this XCD: xcd, xcd + nxcd, ...
   if (mpx == 0 || slot >= mpx * W) return;                      // no more than W workgroups per matrix
   const int K0 = chase_len(n, 0);
   int tasks_left = give_up_after;
 
   int cur = slot % mpx, exhausted = 0;
   while (exhausted < mpx) {
-    const int b = xcd + 8 * cur;
+    const int b = xcd + nxcd * cur;
     int* prog = progress + (size_t)b * n;
     // ---- claim the next sweep of matrix b (the counter is only ever touched from this XCD)
     if (tid == 0) s_claim = atomicAdd(next_sweep + b, 1);
@@ -1311,6 +1311,598 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         }
       }
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Pair form of the persistent chase (round 4): ONE workgroup walks TWO consecutive sweeps down the band.
+//
+// Why: every byte a task stores leaves the XCD's L2 (the L2 writes through), so the chase moves 96 KB of HBM traffic
+// per task whatever the cache does -- 1.75 TB per 64 x n = 6000 step, the floor of both older forms -- and every
+// hand-off between sweeps goes through memory.  Sweep s + 1 touches, two tasks later, the very blocks sweep s has just
+// left (shifted by one row and one column).  Here team A (threads 0..255) runs the tasks of sweep sA = 2 p and leaves
+// its blocks in LDS; team B (threads 256..511) runs sweep sB = sA + 1 two positions behind and takes its blocks from
+// there: per PAIR of tasks one block set is read from memory (A) and one is written (B) -- half the traffic -- and the
+// A -> B hand-off costs a workgroup barrier instead of store drain + publish + poll + L2 loads.
+//
+// LDS: a ring of three position slots (E 64 x 65 + D packed lower, 49 920 B each): at step m, A works on position m
+// (slot m % 3), B on position m - 2, position m - 1 waits.  B's block at position k is A's block shifted by (1, 1):
+//   E'(i, j) = E_k(i + 1, j + 1),  E'(i, 63) = D_k(i + 1, 0),  E'(63, 63) = E_{k+1}(0, 0),  E'(63, j < 63) = 0
+//   D'(i, j) = D_k(i + 1, j + 1),  D'(63, j) = E_{k+1}(0, j + 1),  D'(63, 63) = D_{k+1}(0, 0)
+// so every element A leaves behind is consumed by exactly one task of B -- except the entries A has just annihilated
+// (E_k(1.., 0)), which no block of sweep sB covers, and the corner D_0(0, 0) of A's first block, which has no task of B
+// above it: A stores those to the band itself.  tools/models/bulge_pair_model.py is the NumPy model of this data flow.  The column sums a task needs (z = E^T v and
+// the strictly-lower half of p = D v) read an LDS image of the block: for A that is its slot, for B the slot it has just
+// emptied.  Both teams execute ONE instruction stream with the same nine workgroup barriers per step; what differs is
+// where blocks come from (A: memory through the L2, B: LDS) and go to (A: LDS, B: memory).
+//
+// Dependences across workgroups are those of k_bulge_chase: pairs are CLAIMED in order (so the owner of sweep sA - 1 is
+// running or done), A's task k starts when progress[sA - 1] >= k + 2, B publishes progress[sB] after its stores have
+// drained; all workgroups of a matrix sit on one XCD.  When a wait runs into its bound or the stop flag is up, the
+// workgroup writes its live slots back to the band and publishes both sweeps' counts, so the per-wavefront launches can
+// finish the chase from the counters exactly as after k_bulge_chase.
+// Diagnostic build (-DPAIR_STAMPS): shader cycles of thread 0 between the barriers of every step, summed over all steps
+// of all workgroups since the last read (sc_dbg_pair_stamps, tools/pair_stamps.py); nothing of it in the normal build.
+#ifdef PAIR_STAMPS
+__device__ unsigned long long g_pair_stamps[16];
+#define PAIR_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#define PAIR_ACC(slot, a, b) if (tid == 0) atomicAdd(&g_pair_stamps[slot], (b) - (a));
+#else
+#define PAIR_STAMP(var)
+#define PAIR_ACC(slot, a, b)
+#endif
+
+constexpr int kSlotE = kB * (kB + 1);          // E block, row stride 65 (conflict-free column access)
+constexpr int kSlotD = kB * (kB + 1) / 2;      // D block, lower triangle packed by rows: (i, j) at i (i + 1) / 2 + j
+constexpr int kSlot = kSlotE + kSlotD;
+constexpr int kTeamLds = 2 * kB + kB + 4 * kB + 8;   // vbuf[2][64], u[64], red[256], tau, beta (+ pad)
+constexpr size_t kPairLdsBytes = sizeof(double) * (3 * kSlot + 2 * kTeamLds);
+
+// The common step of k_bulge_pair: both teams at work on full 64-row blocks, neither at a sweep start.  Same barriers
+// and the same arithmetic as the general form inside the kernel, without its masks, clamps and case distinctions -- the
+// step is bound by instruction issue, not by flops -- and one instruction stream per team: A (TEAM 0) loads its blocks
+// from the band and leaves them in its LDS slot, B (TEAM 1) takes the shifted blocks from the slots and stores to the band.
+typedef double __attribute__((address_space(3)))* ldptr;   // LDS: ds_read / ds_write, never flat
+struct PairStepArgs {
+  double* ab;        // band of this matrix
+  double* vd;        // its diamonds
+  double* tau2;
+  ldptr slots;       // LDS: ring of three position slots
+  ldptr vbuf, u, red, sc;   // LDS: this team's vectors
+  int* prog;
+  int s, k;          // this team's sweep and position
+  size_t dia;
+  int cc;
+  int tid;
+};
+
+template <int TEAM>
+__device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& tau_p, int& pend_k) {
+  const int tid = P.tid, tt = tid & 255, i = tid & 63, q = (tid >> 6) & 3;
+  const int k = P.k, s = P.s;
+  const int r0 = s + 1 + k * kB;
+  ldptr vp = P.vbuf + ((k + 1) & 1) * kB;
+  ldptr vn = P.vbuf + (k & 1) * kB;
+  ldptr Eimg = P.slots + (k % 3) * kSlot;   // A: its slot; B: the slot it consumes, then its scratch image
+  ldptr Dimg = Eimg + kSlotE;
+  ldptr red = P.red;
+  ldptr u = P.u;
+  gdptr colbase_k = wave_uniform(P.ab + (size_t)r0 * kLdab);
+  gdptr ebase_k = wave_uniform(P.ab + (size_t)(r0 - kB) * kLdab);
+  const unsigned o_e = (unsigned)(kB + i + q * 16 * (kLdab - 1));   // E(i, 16 q + c) at ebase[o_e + c (kLdab - 1)]
+  const unsigned o_d = (unsigned)(i + q * 16 * (kLdab - 1));        // D(i, 16 q + c) at colbase[o_d + c (kLdab - 1)]
+  double d16[16], t16[16], vr[16];
+  if (TEAM == 0) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t16[c] = ld_l2(ebase_k + (o_e + (unsigned)(c * (kLdab - 1))));
+    // (entries above the diagonal: whatever lies in front of the column, masked in step (5); D is not needed before)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d16[c] = ld_l2(colbase_k + (o_d + (unsigned)(c * (kLdab - 1))));
+  } else {
+    const ldptr En = P.slots + ((k + 1) % 3) * kSlot;
+    const int i1 = min(i + 1, kB - 1);
+    const ldptr rowD = i < kB - 1 ? Dimg + i1 * (i1 + 1) / 2 : En;
+    const ldptr rowE = Eimg + i1 * (kB + 1) + 1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d16[c] = rowD[q * 16 + c + 1];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t16[c] = i < kB - 1 ? rowE[q * 16 + c] : 0.0;
+    if (q == 3) {
+      const double dcol = Dimg[i1 * (i1 + 1) / 2];
+      t16[15] = i < kB - 1 ? dcol : En[0];
+      if (i == kB - 1) d16[15] = En[kSlotE];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous step's stores are in the L2
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) vr[c] = vp[q * 16 + c];
+  lds_barrier();                                                                  // [1]
+  if (TEAM == 1) {
+    if (tt == 0 && pend_k >= 0) __hip_atomic_store(P.prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_k = k;
+  }
+  {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a += t16[c] * vr[c];
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                  // [2]
+  {
+    const double ui = tau_p * ((red[i] + red[kB + i]) + (red[2 * kB + i] + red[3 * kB + i]));
+    ldptr erow = Eimg + i * (kB + 1) + q * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      t16[c] -= ui * vr[c];
+      erow[c] = t16[c];
+    }
+    if (q == 0) {
+      const double x = t16[0];
+      const double t2 = wave_sum(i >= 1 ? x * x : 0.0);
+      const HH h = householder(__shfl(x, 0), t2);
+      vn[i] = i == 0 ? 1.0 : x * h.scale;
+      if (i == 0) { P.sc[0] = h.tau; P.sc[1] = h.beta; }
+    }
+  }
+  lds_barrier();                                                                  // [3]
+#pragma unroll
+  for (int c = 0; c < 16; ++c) vr[c] = vn[q * 16 + c];
+  {
+    double a = 0.0;
+    const ldptr ecol = Eimg + q * 16 * (kB + 1) + i;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a += ecol[c * (kB + 1)] * vr[c];
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                  // [4]
+  if (tt < kB) u[tt] = P.sc[0] * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
+  {
+    ldptr rowp = Dimg + i * (i + 1) / 2 + q * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      d16[c] = q * 16 + c <= i ? d16[c] : 0.0;
+      if (q * 16 + c <= i) rowp[c] = d16[c];
+    }
+  }
+  lds_barrier();                                                                  // [5]
+  {
+    const double vi = vn[i];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t16[c] -= vi * u[q * 16 + c];
+    if (q == 0) t16[0] = i == 0 ? P.sc[1] : 0.0;
+    if (TEAM == 0) {
+      ldptr erow = Eimg + i * (kB + 1) + q * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) erow[c] = t16[c];
+      if (q == 0 && i >= 1) ebase_k[(unsigned)(kB + i)] = 0.0;   // the annihilated entries, see the kernel's header
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) ebase_k[o_e + (unsigned)(c * (kLdab - 1))] = t16[c];
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int ii = q * 16 + c;
+      const double dcolv = Dimg[ii * (ii + 1) / 2 + min(i, ii)];
+      a += (d16[c] + (ii > i ? dcolv : 0.0)) * vr[c];     // row half + column half share vn[16 q + c]
+    }
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                  // [6]
+  const double tau_f = P.sc[0];
+  if (tt < kB) {
+    const double pp = tau_f * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
+    const double dot = wave_sum(pp * vn[tt]);
+    u[tt] = pp - 0.5 * tau_f * dot * vn[tt];
+  }
+  lds_barrier();                                                                  // [7]
+  {
+    const double vi = vn[i], wi = u[i];
+    if (TEAM == 0) {
+      ldptr rowp = Dimg + i * (i + 1) / 2 + q * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (q * 16 + c <= i) rowp[c] = d16[c] - vi * u[q * 16 + c] - wi * vr[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (q * 16 + c <= i) colbase_k[o_d + (unsigned)(c * (kLdab - 1))] = d16[c] - vi * u[q * 16 + c] - wi * vr[c];
+    }
+    double* vd = P.vd + P.dia * kDiaSize + (size_t)P.cc * kG + P.cc;
+    if (tt < kB) vd[(size_t)tt * kG] = vn[tt];
+    if (tt == 0) P.tau2[P.dia * kG + P.cc] = tau_f;
+    tau_p = tau_f;
+  }
+}
+
+// The general step of k_bulge_pair (sweep starts, partial last blocks, steps in which only one team has a position): the
+// same barriers as pair_step_full, with every mask and case distinction.  Not inlined: it runs in a few steps per pair
+// only, and its registers would otherwise be charged to the common step.
+struct PairGenArgs {
+  double* ab;
+  double* vd;
+  double* tau2;
+  ldptr slots;
+  ldptr vbuf, u, red, sc;
+  int* prog;
+  int* sweeps_done;
+  int n, s, k, my_len, team, to_lds;
+  size_t dia0;
+  int cc, tid;
+};
+struct PairCarry {
+  double tau_p;
+  int pend_k;
+};
+
+__device__ __noinline__ PairCarry pair_step_general(const PairGenArgs P, double tau_p, int pend_k) {
+  double* const ab = P.ab;
+  const ldptr slots = P.slots, vbuf = P.vbuf, u = P.u, red = P.red, sc = P.sc;
+  int* const prog = P.prog;
+  const int n = P.n, s = P.s, k = P.k, my_len = P.my_len, team = P.team, cc = P.cc, tid = P.tid;
+  const bool to_lds = P.to_lds != 0;
+  const size_t dia0 = P.dia0;
+  const int tt = tid & 255, i = tid & 63, q = (tid >> 6) & 3;
+  const bool active = k >= 0 && k < my_len;
+  const bool first = k == 0;
+  const bool eph = active && !first;            // this team has an off-diagonal block in this step
+  const int kk = active ? k : 0;
+  const int r0 = s + 1 + kk * kB;
+  const int L = active ? min(kB, n - r0) : 0;
+  ldptr vp = vbuf + ((kk + 1) & 1) * kB;   // reflector of this sweep's previous task
+  ldptr vn = vbuf + (kk & 1) * kB;
+  ldptr Eimg = slots + (kk % 3) * kSlot;   // A: its slot; B: the slot it consumes, then its scratch image
+  ldptr Dimg = Eimg + kSlotE;
+  const size_t dia = dia0 + kk;
+  gdptr colbase_k = wave_uniform(ab + (size_t)r0 * kLdab);                        // AB(r0, r0)
+  gdptr ebase_k = wave_uniform(ab + (size_t)(r0 - (first ? 0 : kB)) * kLdab);    // AB(r0 - kB, r0 - kB)
+
+  // ---- (1) the blocks into registers: thread (i, q) holds row i, columns 16 q .. 16 q + 15
+  double d16[16], t16[16];
+  double xcol = 0.0;   // sweep start (k == 0, first wave of the team): x = AB(s + 1 + i, s)
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { d16[c] = 0.0; t16[c] = 0.0; }
+  if (active && team == 0) {
+    // (E first: it is needed at once; D is not touched before step (5), its loads land behind steps (2)-(4))
+    if (!first) {
+      const int ic = min(i, L - 1);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int jj = q * 16 + c;
+        t16[c] = ld_l2(ebase_k + (unsigned)((kB + ic - jj) + jj * kLdab));
+      }
+    } else if (q == 0) {
+      gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
+      xcol = ld_l2(col_s + (unsigned)(1 + min(i, L - 1)));
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int jc = min(q * 16 + c, L - 1);
+      const int ic = min(max(i, jc), L - 1);
+      d16[c] = ld_l2(colbase_k + (unsigned)((ic - jc) + jc * kLdab));
+    }
+  } else if (active) {
+    // B's block = A's, shifted by (1, 1) (see the header); row 63 comes from row 0 of A's next position.  Whatever is
+    // read from a slot that does not exist (A's last position: then L <= 63) is masked out below
+    const ldptr En = slots + ((kk + 1) % 3) * kSlot;
+    const int i1 = min(i + 1, kB - 1);
+    const ldptr rowD = i < kB - 1 ? Dimg + i1 * (i1 + 1) / 2 : En;   // D'(i, jj) = rowD[jj + 1]
+    const ldptr rowE = Eimg + i1 * (kB + 1) + 1;                     // E'(i, jj) = rowE[jj]  (i, jj < 63)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d16[c] = rowD[q * 16 + c + 1];
+    if (!first) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t16[c] = i < kB - 1 ? rowE[q * 16 + c] : 0.0;
+    }
+    if (q == 3) {   // column 63: E'(i, 63) = D_k(i + 1, 0); corner (63, 63): D_{k+1}(0, 0) and E_{k+1}(0, 0)
+      const double dcol = Dimg[i1 * (i1 + 1) / 2];
+      if (!first) t16[15] = i < kB - 1 ? dcol : En[0];
+      if (i == kB - 1) d16[15] = En[kSlotE];
+    }
+    if (first && q == 0) xcol = i < kB - 1 ? Dimg[i1 * (i1 + 1) / 2] : En[0];
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t16[c] = i < L ? t16[c] : 0.0;
+  xcol = i < L ? xcol : 0.0;
+  // B (and a lone A): the stores of the previous step are in the L2 -- a wait that overlaps A's for its loads
+  // (A's own few stores -- zeros, corner, reflector -- are older than its next loads, whose data it waits for: in
+  // order; once A has run out of positions it drains like B)
+  if (!to_lds || !active) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();                                                                    // [1] B's slot reads are done
+  if (tt == 0 && pend_k >= 0) {   // publish the previous step's task
+    __hip_atomic_store(prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pend_k + 1 == my_len) atomicAdd(P.sweeps_done, 1);
+  }
+  pend_k = -1;
+  
+  // ---- (2) u = tau_p E vp: partial sums over this wave's 16 columns
+  if (eph) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a += t16[c] * vp[q * 16 + c];
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                    // [2]
+  // ---- (3) E <- E (I - tau_p vp vp^T) in registers + its LDS image; new reflector; image of D (packed lower)
+  if (eph) {
+    const double ui = tau_p * ((red[i] + red[kB + i]) + (red[2 * kB + i] + red[3 * kB + i]));
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      t16[c] -= ui * vp[q * 16 + c];
+      Eimg[i * (kB + 1) + q * 16 + c] = t16[c];
+    }
+    if (q == 0) xcol = t16[0];
+  }
+  if (active && q == 0) {
+    const double t2 = wave_sum((i >= 1 && i < L) ? xcol * xcol : 0.0);
+    const HH h = householder(__shfl(xcol, 0), t2);
+    vn[i] = i == 0 ? 1.0 : (i < L ? xcol * h.scale : 0.0);
+    if (i == 0) { sc[0] = h.tau; sc[1] = h.beta; }
+    if (first && i < L) {   // the annihilated column: AB(s + 1 .., s) = (beta, 0, ..)
+      gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
+      col_s[(unsigned)(1 + i)] = i == 0 ? h.beta : 0.0;
+    }
+  }
+  lds_barrier();                                                                    // [3]
+    // ---- (4) z_j = sum_i E[i, j] vn_i: thread (j = i, rows 16 q ..)
+  if (eph) {
+    double a = 0.0;
+#pragma unroll
+    for (int ii = q * 16; ii < q * 16 + 16; ++ii) a += Eimg[ii * (kB + 1) + i] * vn[ii];
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                    // [4]
+  if (eph && tt < kB) u[tt] = sc[0] * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
+  // image of D (packed lower) for the column half of p = D vn; A's D loads have had steps (2)-(4) to land
+#pragma unroll
+  for (int c = 0; c < 16; ++c) d16[c] = (i < L && q * 16 + c <= i) ? d16[c] : 0.0;
+  if (active) {
+    ldptr rowp = Dimg + i * (i + 1) / 2 + q * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (q * 16 + c <= i) rowp[c] = d16[c];
+  }
+  lds_barrier();                                                                    // [5]
+    // ---- (6) E <- H E, first column = beta e1: to LDS (A) or to the band (B); then p = D vn, row half from the
+  // registers, strictly-lower (column) half from the packed image
+  if (eph) {
+    const double vi = vn[i], beta = sc[1];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int jj = q * 16 + c;
+      double e = t16[c] - vi * u[jj];
+      if (jj == 0) e = i == 0 ? beta : 0.0;
+      if (to_lds) {
+        Eimg[i * (kB + 1) + jj] = i < L ? e : 0.0;
+        // the annihilated entries (first column below its first row) lie outside every block of sweep sB: B's shifted
+        // blocks never write them back, so A zeroes them in the band itself
+        if (jj == 0 && i >= 1 && i < L) ebase_k[(unsigned)(kB + i)] = 0.0;
+      } else if (i < L) {
+        ebase_k[(unsigned)((kB + i - jj) + jj * kLdab)] = e;
+      }
+    }
+  }
+  if (active) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a += d16[c] * vn[q * 16 + c];          // (entries above the diagonal are zero)
+#pragma unroll
+    for (int ii = q * 16; ii < q * 16 + 16; ++ii) {
+      const double dv = Dimg[ii * (ii + 1) / 2 + min(i, ii)];
+      a += ii > i ? dv * vn[ii] : 0.0;
+    }
+    red[q * kB + i] = a;
+  }
+  lds_barrier();                                                                    // [6]
+    const double tau_now = sc[0];
+  if (active && tt < kB) {
+    const double pp = tau_now * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
+    const double dot = wave_sum(pp * vn[tt]);
+    u[tt] = pp - 0.5 * tau_now * dot * vn[tt];
+  }
+  lds_barrier();                                                                    // [7]
+    // ---- (8) D <- D - vn w^T - w vn^T: to LDS (A) or to the band (B); the reflector goes into its diamond
+  if (active) {
+    const double vi = vn[i], wi = u[i];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int jj = q * 16 + c;
+      if (jj <= i) {
+        const double val = d16[c] - vi * u[jj] - wi * vn[jj];
+        if (to_lds) {
+          Dimg[i * (i + 1) / 2 + jj] = i < L ? val : 0.0;
+          // row 0 of a block is consumed by B's task one position up -- which does not exist for A's first block:
+          // its corner AB(sA + 1, sA + 1) is final already and goes to the band here
+          if (first && i == 0) colbase_k[0] = val;
+        } else if (i < L) {
+          colbase_k[(unsigned)((i - jj) + jj * kLdab)] = val;
+        }
+      }
+    }
+    double* vd = P.vd + dia * kDiaSize + (size_t)cc * kG + cc;
+    if (tt < L) vd[(size_t)tt * kG] = vn[tt];
+    if (tt == 0) P.tau2[dia * kG + cc] = tau_now;
+    tau_p = tau_now;
+    if (!to_lds) pend_k = k;   // published once the stores have drained: behind the next step's loads
+  }
+  return PairCarry{tau_p, pend_k};
+}
+
+// (the few fields of the band workspace's layout the kernel needs, instead of all of SbLayout in scalar registers)
+struct PairLayout {
+  int n;
+  long long slab, ab, vd, tau2;
+};
+
+__global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_all, PairLayout SL, int batch, int W, int nxcd,
+                                                      int* __restrict__ progress, int* __restrict__ next_pair,
+                                                      int* __restrict__ ctl, int give_up_after) {
+  extern __shared__ double pair_lds[];
+  __shared__ int s_go, s_claim, s_xcd, s_slot;
+
+  const int n = SL.n;
+  const int tid = threadIdx.x;
+  // (the wave number is uniform over a wave: told to the compiler, so that everything derived from team and q -- the
+  // position, `active`, `first`, L -- lives in scalar registers and the branches on it are scalar branches)
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int tt = tid & 255;
+  double* const slots = pair_lds;
+  double* const tl = pair_lds + 3 * kSlot + team * kTeamLds;
+  double* const vbuf = tl;
+  double* const u = tl + 2 * kB;
+  double* const red = tl + 3 * kB;
+  double* const sc = tl + 7 * kB;   // [0] tau, [1] beta of the reflector being generated
+
+  if (tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    s_xcd = (int)(id & 7u) % nxcd;
+    s_slot = atomicAdd(ctl + 2 + s_xcd, 1);
+  }
+  __syncthreads();
+  const int xcd = s_xcd, slot = s_slot;
+  const int mpx = xcd < batch ? (batch - xcd + nxcd - 1) / nxcd : 0;   // matrices of this XCD: xcd, xcd + nxcd, ...
+  if (mpx == 0 || slot >= mpx * W) return;
+  const int K0 = chase_len(n, 0);
+  int steps_left = give_up_after;
+
+  int cur = slot % mpx, exhausted = 0;
+  while (exhausted < mpx) {
+    const int b = xcd + nxcd * cur;
+    int* prog = progress + (size_t)b * n;
+    if (tid == 0) s_claim = atomicAdd(next_pair + b, 1);
+    __syncthreads();
+    const int sA = 2 * __builtin_amdgcn_readfirstlane(s_claim);
+    __syncthreads();
+    if (sA > n - 3) {
+      ++exhausted;
+      cur = cur + 1 < mpx ? cur + 1 : 0;
+      continue;
+    }
+    exhausted = 0;
+    double* sb = sb_all + (size_t)b * SL.slab;
+    double* ab = sb + SL.ab;
+    const bool hasB = sA + 1 <= n - 3;
+    const int lenA = chase_len(n, sA), lenB = hasB ? chase_len(n, sA + 1) : 0;
+    const int s = sA + team;                 // this team's sweep
+    const int my_len = team ? lenB : lenA;
+    const int S = s / kG, cc = s - S * kG;
+    const size_t dia0 = (size_t)S * K0 - (size_t)S * (S - 1) / 2;
+    const int len_prev = sA > 0 ? chase_len(n, sA - 1) : 0;
+    const bool to_lds = team == 0 && hasB;   // A's results stay in LDS (a lone last sweep writes to memory itself)
+    double tau_p = 0.0;
+
+    const int nsteps = hasB ? lenA + 2 : lenA;
+    int have_c = 0;      // thread 0: last value seen of the predecessor's counter (it only grows)
+    int pend_k = -1;     // task of this team whose stores are on their way: published behind the next step's loads
+    for (int m = 0; m < nsteps; ++m) {
+      // ---- wait for the predecessor pair (A's dependence; B's are inside the workgroup).  The counter is read again only
+      // when the cached value does not cover this step; the stop flag with it, and every eighth step
+      PAIR_STAMP(ts0)
+      if (tid == 0) {
+        const int need = (sA > 0 && m < lenA) ? min(m + 2, len_prev) : 0;
+        int go = 1;
+        if (have_c < need || (m & 7) == 0) {
+          const int stop0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int have = sA > 0 ? __hip_atomic_load(prog + sA - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          if (stop0) go = 0;
+          long spins = 0;
+          while (go && have < need) {
+            // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
+            ++spins;
+            if (spins > (1L << 21) ||
+                ((spins & 15) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                ctl[10] = b; ctl[11] = sA; ctl[12] = m;
+              }
+              __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              go = 0;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            have = __hip_atomic_load(prog + sA - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          have_c = have;
+        }
+        s_go = go;
+      }
+      lds_barrier();   // [0] (also: A's last slot writes of the previous step are ordered before B's reads below)
+      if (!s_go) {
+        // ---- give up between steps.  First the pending publish (its stores drained), then: A has finished positions
+        // < min(m, lenA), B positions < m - 2; what A left for B (positions m - 2 and m - 1) goes back to the band, and
+        // both counts are published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tt == 0 && pend_k >= 0) __hip_atomic_store(prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hasB) {
+          for (int pos = max(m - 2, 0); pos < min(m, lenA); ++pos) {
+            const double* Es = slots + (pos % 3) * kSlot;
+            const double* Ds = Es + kSlotE;
+            const int r0p = sA + 1 + pos * kB;
+            const int Lp = min(kB, n - r0p);
+            // (row 0 of the older slot has been consumed and rewritten in the band by B's task one position up)
+            const int i_lo = (pos == m - 2 && pos >= 1) ? 1 : 0;
+            if (pos > 0)
+              for (int e = tid; e < kB * kB; e += 512) {
+                const int ii = e & 63, jj = e >> 6;
+                if (ii >= i_lo && ii < Lp) ab[(size_t)(r0p - kB + jj) * kLdab + (kB + ii - jj)] = Es[ii * (kB + 1) + jj];
+              }
+            for (int e = tid; e < kB * kB; e += 512) {
+              const int ii = e & 63, jj = e >> 6;
+              if (ii >= jj && ii >= i_lo && ii < Lp) ab[(size_t)(r0p + jj) * kLdab + (ii - jj)] = Ds[ii * (ii + 1) / 2 + jj];
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            __hip_atomic_store(prog + sA, min(m, lenA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(prog + sA + 1, min(max(m - 2, 0), lenB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        return;
+      }
+
+      PAIR_STAMP(ts1)
+      const int k = team ? m - 2 : m;
+      // ---- the common step: both teams at work on full 64-row blocks, neither at a sweep start (pair_step_full)
+      if (hasB && m >= 3 && m < lenA && sA + 1 + (m + 1) * kB <= n) {
+        PairStepArgs pa{ab, sb + SL.vd, sb + SL.tau2, (ldptr)slots, (ldptr)vbuf, (ldptr)u, (ldptr)red, (ldptr)sc, prog, s, k,
+                        dia0 + k, cc, tid};
+        if (team == 0) pair_step_full<0>(pa, tau_p, pend_k);
+        else pair_step_full<1>(pa, tau_p, pend_k);
+#ifdef PAIR_STAMPS
+        if (tid == 0) { atomicAdd(&g_pair_stamps[8], 1ull); atomicAdd(&g_pair_stamps[9], 1ull); }
+#endif
+      } else {
+        PairGenArgs ga{ab, sb + SL.vd, sb + SL.tau2, (ldptr)slots, (ldptr)vbuf, (ldptr)u, (ldptr)red, (ldptr)sc, prog,
+                       ctl + 16 + xcd, n, s, k, my_len, team, to_lds ? 1 : 0, dia0, cc, tid};
+        const PairCarry pc = pair_step_general(ga, tau_p, pend_k);
+        tau_p = pc.tau_p;
+        pend_k = pc.pend_k;
+      }
+      // (no barrier here: the next step's [0] orders this step's slot writes before their readers, and nothing else of
+      // the next step touches LDS before it)
+#ifdef PAIR_STAMPS
+      if (tid == 0) atomicAdd(&g_pair_stamps[8], 1ull);
+#endif
+      if (tid == 0) {
+        if (to_lds && m + 1 == lenA) atomicAdd(ctl + 16 + xcd, 1);   // (A's last task; its count is published below)
+        // test hook (sc_dbg_set_chase): raise the time-out flag after that many steps of this workgroup
+        if (give_up_after > 0 && --steps_left == 0) {
+          ctl[1] = give_up_after;
+          __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    // ---- end of the pair: the last task's stores, then its count; sweep sA lived in LDS until B had consumed it -- its
+    // count only matters to a take-over and is complete now
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tt == 0 && pend_k >= 0) {
+      __hip_atomic_store(prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pend_k + 1 == my_len) atomicAdd(ctl + 16 + xcd, 1);
+    }
+    if (tid == 0 && hasB) __hip_atomic_store(prog + sA, lenA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -2375,23 +2967,41 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     static const int env_persist = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PERSISTENT"); return e ? atoi(e) : 1; }();
     const int persist = ctx->chase_mode >= 0 ? ctx->chase_mode : env_persist;
     bool chased = false;
-    // it pays while the stage is latency-bound: measured crossover batch * n / 128 ~ 2800 (tools/bulge_sweep.py,
-    // profiles/r03_bulge_sweep.txt: 32 x n = 6000 195 vs 253 ms, 64 x n = 6000 a tie at 436; round 2, with one workgroup
-    // per CU for want of registers: ~ 1200); beyond that the per-wavefront launches on several streams take over.  With
+    // Which form (profiles/r04_bulge_sweep.txt, batch x n: pair / one sweep per workgroup / per-wavefront launches, ms):
+    // 16 x 6000: 126 / 115 / 169, 32 x 3000: 63 / 56 / 82, 64 x 3000: 92 / 99 / 124, 32 x 6000: 182 / 223 / 256,
+    // 64 x 6000: 335 / 435 / 436.  While the stage is latency-bound (batch * n / 128 <= 1100) one sweep per workgroup has
+    // the shorter dependent chain; above that the stage is bound by bytes and the pair form moves half of them.  With
     // fewer matrices than XCDs (a matrix is confined to one XCD) only while the order is moderate: a single n = 24000
     // matrix chases 1.6 x faster with its ~188 tasks per wavefront spread over the whole chip (411 vs 676 ms)
+    static const bool use_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return !e || atoi(e) != 0; }();
+    static const int force_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return e ? atoi(e) : -1; }();
+    static const bool pair_attr = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kPairLdsBytes) == hipSuccess;
+    }();
+    const long long work = (long long)batch * n / 128;
+    // SPRINGCRAFT_BULGE_PAIR = 0: never the pair form, 2: the pair form for every persistent chase (tests), else by size
+    const bool pair = ctx->chase_form >= 0 ? (ctx->chase_form == 1 && pair_attr)
+                                           : use_pair && pair_attr && (force_pair == 2 || (work > 1100 && batch >= 8));
     const bool want_chase =
-        persist == 2 || (persist == 1 && (long long)batch * n / 128 <= 2800 && (batch >= 8 || n <= 6144));
+        persist == 2 || (persist == 1 && (pair || (work <= 2800 && (batch >= 8 || n <= 6144))));
     // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):
     // every further attempt could cost another bound's worth of spinning before the fallback
+    // XCDs of this device: the kernels bind matrix b to XCD b mod nxcd (an MI355X in SPX mode has 8 XCDs of 32 CUs; a
+    // partition of it has fewer, and a matrix bound to an XCD that is not there would never be claimed)
+    const int nxcd = std::max(1, std::min(8, ctx->num_cus / 32));
     if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
-      const int slots_per_xcd = per_cu * ctx->num_cus / 8;
-      const int mpx = (batch + 7) / 8;   // matrices per XCD (XCD 0 has the most)
+      if (pair) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_pair, 512, kPairLdsBytes) != hipSuccess) per_cu = 0;
+      } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
+      }
+      const int slots_per_xcd = per_cu * ctx->num_cus / nxcd;
+      const int mpx = (batch + nxcd - 1) / nxcd;   // matrices per XCD (XCD 0 has the most)
       // workgroups per matrix: all the XCD's slots divided by its matrices, but no more than sweeps can be in flight
-      // (every sweep trails its predecessor by two tasks)
-      const int useful = std::max(8, chase_len(n, 0) / 2 + 1);
+      // (every sweep trails its predecessor by two tasks; a pair its predecessor pair by three steps)
+      const int useful = pair ? std::max(4, chase_len(n, 0) / 3 + 2) : std::max(8, chase_len(n, 0) / 2 + 1);
       const int W = slots_per_xcd > 0 ? std::max(1, std::min(useful, slots_per_xcd / mpx)) : 0;
       if (W >= 1) {
         // progress counters (batch x n) | claim counters (batch) | ctl
@@ -2405,10 +3015,15 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
         SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + next_bytes + ctl_bytes, st));
         // the dispatcher deals workgroups round-robin over the XCDs, so 8 x (workgroups one XCD needs) gives every XCD
         // its share; the kernel does not rely on it (a short-changed XCD is just slower, see the kernel's header)
-        const int grid = 8 * std::min(slots_per_xcd, mpx * W);
+        const int grid = nxcd * std::min(slots_per_xcd, mpx * W);
         t_bulge.start();
-        hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, d_prog, d_next,
-                           d_ctl, ctx->chase_give_up);
+        if (pair)
+          hipLaunchKernelGGL(k_bulge_pair, dim3((unsigned)grid), dim3(512), kPairLdsBytes, st, d_sb_ws,
+                             PairLayout{SL.n, SL.slab, SL.ab, SL.vd, SL.tau2}, batch, W, nxcd, d_prog, d_next, d_ctl,
+                             ctx->chase_give_up);
+        else
+          hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
+                             d_next, d_ctl, ctx->chase_give_up);
         const hipError_t le = hipGetLastError();
         t_bulge.stop();
         if (le == hipSuccess) {
@@ -2421,6 +3036,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
             ctx->chase_tickets[x] = h_ctl[2 + x];
           }
           ++ctx->cnt_chase_launches;
+          if (pair) ++ctx->cnt_pair_launches;
           ctx->cnt_chase_sweeps += sweeps;
           const bool complete = sweeps == (long long)batch * (n - 2);
           if (h_ctl[0] || !complete) {
@@ -2434,6 +3050,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
               ctx->chase_wait[0] = h_ctl[10]; ctx->chase_wait[1] = h_ctl[11]; ctx->chase_wait[2] = h_ctl[12];
             } else if (!h_ctl[0]) {
               ++ctx->cnt_chase_incomplete;
+              // an XCD that owns matrices drew no ticket: this device does not deal workgroups the way the kernel assumes
+              //  -- do not pay for a launch + take-over on every further solve of this context
+              for (int x = 0; x < nxcd && x < batch; ++x)
+                if (h_ctl[2 + x] == 0) ctx->chase_ok = 0;
             }
             ++ctx->cnt_chase_resumed;
             t_bulge.start();
@@ -2595,6 +3215,17 @@ extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
 
 // ---- diagnostic build only: {sum t(E in LDS), sum t(E stored) [tasks with k > 0], sum t(D in LDS), sum t(end), tasks,
 // tasks with k > 0}, cycles since the task's start; reset after the read
+extern "C" int sc_dbg_pair_stamps(unsigned long long* out16) {
+#ifdef PAIR_STAMPS
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pair_stamps), 128) != hipSuccess) return 5;
+  const unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, 128) == hipSuccess ? 0 : 5;
+#else
+  (void)out16;
+  return 1;
+#endif
+}
+
 extern "C" int sc_dbg_bulge_stamps(unsigned long long* out6) {
 #ifdef BULGE_STAMPS
   if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_bulge_stamps), 48) != hipSuccess) return 5;

@@ -206,10 +206,14 @@ def _lib_dbg():
     return L
 
 
-@pytest.mark.parametrize("n,batch", [(1200, 8), (1030, 32), (1030, 1), (520, 3)])
+@pytest.mark.parametrize("n,batch", [(1200, 8), (1030, 32), (1030, 1), (520, 3), (259, 9), (322, 2)])
 @pytest.mark.parametrize("give_up", [0, 5, 100])
-def test_persistent_chase_and_resume(n, batch, give_up):
+@pytest.mark.parametrize("form", [3, 4])
+def test_persistent_chase_and_resume(n, batch, give_up, form):
     """
+    (form 3: two sweeps per workgroup through LDS, k_bulge_pair -- the give-up then also exercises the write-back of the
+    LDS slots; form 4: one sweep per workgroup, k_bulge_chase; orders with partial last blocks and an odd sweep count
+    included.)
     The persistent bulge chase (forced on through the debug entry) as ONE batched solve -- several matrices per XCD at
     batch 32, one XCD without a matrix at batch 3 -- and the event counters of the context: without the test hook the
     chase must finish every sweep itself (no time-out, no take-over by the per-wavefront launches); with the hook
@@ -228,7 +232,7 @@ def test_persistent_chase_and_resume(n, batch, give_up):
     ctx = _hip.Context(0)
     try:
         ctx.set_two_stage(True)
-        ctx.check(L.sc_dbg_set_chase(ctx.handle, 2, give_up))
+        ctx.check(L.sc_dbg_set_chase(ctx.handle, form, give_up))
         a = torch.from_numpy(mats.copy()).cuda()
         w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
         v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
@@ -236,8 +240,10 @@ def test_persistent_chase_and_resume(n, batch, give_up):
                                     C.c_void_p(v.data_ptr())))
         ctx.synchronize()
         cnt = {k: ctx.counter(k) for k in ("chase_launches", "chase_timeouts", "chase_incomplete", "chase_resumed",
-                                           "chase_sweeps", "stepwise_chases", "chase_xcd_min", "chase_xcd_max")}
+                                           "chase_sweeps", "stepwise_chases", "chase_xcd_min", "chase_xcd_max",
+                                           "chase_pair_launches")}
         assert cnt["chase_launches"] == 1 and cnt["stepwise_chases"] == 0, cnt
+        assert cnt["chase_pair_launches"] == (1 if form == 3 else 0), cnt
         assert cnt["chase_timeouts"] == 0 and cnt["chase_incomplete"] == 0, cnt
         if give_up == 0:
             assert cnt["chase_resumed"] == 0 and cnt["chase_sweeps"] == batch * (n - 2), cnt

@@ -1,4 +1,5 @@
-"""Bulge-chasing stage: persistent chase vs one launch per wavefront over (N, batch).  python tools/bulge_sweep.py"""
+"""Bulge-chasing stage over (N, batch): pair form of the persistent chase (k_bulge_pair), one sweep per workgroup
+(k_bulge_chase), one launch per wavefront (k_bulge_step).   python tools/bulge_sweep.py [quick]"""
 import os
 import subprocess
 import sys
@@ -19,13 +20,19 @@ solver.solve(coord); torch.cuda.synchronize()
 t = solver.last_timings()
 print(f"{t['bulge_chasing_ms']:.1f}")
 '''
-for n_atoms in (342, 500, 1000, 2000):
-    for B in (4, 8, 16, 32, 64):
-        if n_atoms * n_atoms * 9 * B * 8 * 4 > 200e9:
-            continue
-        row = []
-        for p in ("2", "0"):   # 2 = persistent chase forced, 0 = off (1, the default, chooses by batch * n)
-            env = dict(os.environ, SPRINGCRAFT_BULGE_PERSISTENT=p)
-            r = subprocess.run([sys.executable, "-c", code, str(n_atoms), str(B)], capture_output=True, text=True, env=env, timeout=300)
-            row.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "fail")
-        print(f"N={n_atoms:5d} n={3 * n_atoms:5d} B={B:3d}: persistent {row[0]:>8s} ms   per-wavefront launches {row[1]:>8s} ms", flush=True)
+MODES = (("pair", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "1"}),
+         ("sweep/wg", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "0"}),
+         ("per-wavefront", {"SPRINGCRAFT_BULGE_PERSISTENT": "0"}))
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+points = [(500, 64), (1000, 16), (1000, 32), (1000, 64), (2000, 8), (2000, 16), (2000, 32), (2000, 64)] if quick else [
+    (n_atoms, B) for n_atoms in (342, 500, 1000, 2000) for B in (4, 8, 16, 32, 64)]
+for n_atoms, B in points:
+    if n_atoms * n_atoms * 9 * B * 8 * 4 > 200e9:
+        continue
+    row = []
+    for name, extra in MODES:
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code, str(n_atoms), str(B)], capture_output=True, text=True, env=env, timeout=300)
+        row.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "fail")
+    print(f"N={n_atoms:5d} n={3 * n_atoms:5d} B={B:3d} (B n / 128 = {B * 3 * n_atoms // 128:5d}): " +
+          "   ".join(f"{name} {v:>7s} ms" for (name, _), v in zip(MODES, row)), flush=True)
