@@ -1341,22 +1341,24 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
 // drained; all workgroups of a matrix sit on one XCD.  When a wait runs into its bound or the stop flag is up, the
 // workgroup writes its live slots back to the band and publishes both sweeps' counts, so the per-wavefront launches can
 // finish the chase from the counters exactly as after k_bulge_chase.
+constexpr int kSlotE = kB * (kB + 1);          // E block, row stride 65 (conflict-free column access)
+constexpr int kSlotD = kB * (kB + 1) / 2;      // D block, lower triangle packed by rows: (i, j) at i (i + 1) / 2 + j
+constexpr int kSlot = kSlotE + kSlotD;
+constexpr int kTeamLds = 2 * kB + kB + 4 * kB + 8;   // vbuf[2][64], u[64], red[256], tau, beta (+ pad)
+constexpr size_t kPairLdsBytes = sizeof(double) * (3 * kSlot + 2 * kTeamLds);
+
 // Diagnostic build (-DPAIR_STAMPS): shader cycles of thread 0 between the barriers of every step, summed over all steps
 // of all workgroups since the last read (sc_dbg_pair_stamps, tools/pair_stamps.py); nothing of it in the normal build.
 #ifdef PAIR_STAMPS
 __device__ unsigned long long g_pair_stamps[16];
 #define PAIR_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
 #define PAIR_ACC(slot, a, b) if (tid == 0) atomicAdd(&g_pair_stamps[slot], (b) - (a));
+#define PAIR_ACC_B(slot, a, b) if (tid == 256) atomicAdd(&g_pair_stamps[slot], (b) - (a));
 #else
 #define PAIR_STAMP(var)
 #define PAIR_ACC(slot, a, b)
+#define PAIR_ACC_B(slot, a, b)
 #endif
-
-constexpr int kSlotE = kB * (kB + 1);          // E block, row stride 65 (conflict-free column access)
-constexpr int kSlotD = kB * (kB + 1) / 2;      // D block, lower triangle packed by rows: (i, j) at i (i + 1) / 2 + j
-constexpr int kSlot = kSlotE + kSlotD;
-constexpr int kTeamLds = 2 * kB + kB + 4 * kB + 8;   // vbuf[2][64], u[64], red[256], tau, beta (+ pad)
-constexpr size_t kPairLdsBytes = sizeof(double) * (3 * kSlot + 2 * kTeamLds);
 
 // The common step of k_bulge_pair: both teams at work on full 64-row blocks, neither at a sweep start.  Same barriers
 // and the same arithmetic as the general form inside the kernel, without its masks, clamps and case distinctions -- the
@@ -1392,12 +1394,10 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
   const unsigned o_e = (unsigned)(kB + i + q * 16 * (kLdab - 1));   // E(i, 16 q + c) at ebase[o_e + c (kLdab - 1)]
   const unsigned o_d = (unsigned)(i + q * 16 * (kLdab - 1));        // D(i, 16 q + c) at colbase[o_d + c (kLdab - 1)]
   double d16[16], t16[16], vr[16];
+  PAIR_STAMP(f0)
   if (TEAM == 0) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) t16[c] = ld_l2(ebase_k + (o_e + (unsigned)(c * (kLdab - 1))));
-    // (entries above the diagonal: whatever lies in front of the column, masked in step (5); D is not needed before)
-#pragma unroll
-    for (int c = 0; c < 16; ++c) d16[c] = ld_l2(colbase_k + (o_d + (unsigned)(c * (kLdab - 1))));
   } else {
     const ldptr En = P.slots + ((k + 1) % 3) * kSlot;
     const int i1 = min(i + 1, kB - 1);
@@ -1412,14 +1412,27 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
       t16[15] = i < kB - 1 ? dcol : En[0];
       if (i == kB - 1) d16[15] = En[kSlotE];
     }
+    PAIR_STAMP(g1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous step's stores are in the L2
+    PAIR_STAMP(g2)
+    PAIR_ACC_B(10, f0, g1) PAIR_ACC_B(11, g1, g2)
   }
 #pragma unroll
   for (int c = 0; c < 16; ++c) vr[c] = vp[q * 16 + c];
+  PAIR_STAMP(fa)
   lds_barrier();                                                                  // [1]
+  PAIR_STAMP(f1)
+  PAIR_ACC(12, f0, fa)
   if (TEAM == 1) {
     if (tt == 0 && pend_k >= 0) __hip_atomic_store(P.prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_k = k;
+  } else {
+    // D is not touched before step (5): its loads are issued here, behind the barrier, so that the other team does not
+    // wait for their issue (under load the memory pipeline takes a block's 16 load instructions per wave slowly: issuing
+    // them costs as much as waiting for the data) and land behind steps (2)-(4).  Entries above the diagonal: whatever
+    // lies in front of the column, masked in step (5).
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d16[c] = ld_l2(colbase_k + (o_d + (unsigned)(c * (kLdab - 1))));
   }
   {
     double a = 0.0;
@@ -1445,6 +1458,7 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
     }
   }
   lds_barrier();                                                                  // [3]
+  PAIR_STAMP(f3)
 #pragma unroll
   for (int c = 0; c < 16; ++c) vr[c] = vn[q * 16 + c];
   {
@@ -1465,6 +1479,7 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
     }
   }
   lds_barrier();                                                                  // [5]
+  PAIR_STAMP(f5)
   {
     const double vi = vn[i];
 #pragma unroll
@@ -1489,6 +1504,7 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
     red[q * kB + i] = a;
   }
   lds_barrier();                                                                  // [6]
+  PAIR_STAMP(f6)
   const double tau_f = P.sc[0];
   if (tt < kB) {
     const double pp = tau_f * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
@@ -1496,6 +1512,7 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
     u[tt] = pp - 0.5 * tau_f * dot * vn[tt];
   }
   lds_barrier();                                                                  // [7]
+  PAIR_STAMP(f7)
   {
     const double vi = vn[i], wi = u[i];
     if (TEAM == 0) {
@@ -1513,6 +1530,13 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
     if (tt == 0) P.tau2[P.dia * kG + P.cc] = tau_f;
     tau_p = tau_f;
   }
+#ifdef PAIR_STAMPS
+  {
+    PAIR_STAMP(f8)
+    PAIR_ACC(1, f0, f1) PAIR_ACC(2, f1, f3) PAIR_ACC(3, f3, f5) PAIR_ACC(4, f5, f6) PAIR_ACC(5, f6, f7) PAIR_ACC(6, f7, f8)
+    PAIR_ACC_B(13, f7, f8)
+  }
+#endif
 }
 
 // The general step of k_bulge_pair (sweep starts, partial last blocks, steps in which only one team has a position): the
@@ -1742,8 +1766,8 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
 
   const int n = SL.n;
   const int tid = threadIdx.x;
-  // (the wave number is uniform over a wave: told to the compiler, so that everything derived from team and q -- the
-  // position, `active`, `first`, L -- lives in scalar registers and the branches on it are scalar branches)
+  // (the team is uniform over a wave: told to the compiler, so that the position, the step's case and the branches on
+  // them are scalar)
   const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int tt = tid & 255;
   double* const slots = pair_lds;
@@ -1871,7 +1895,7 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
         if (team == 0) pair_step_full<0>(pa, tau_p, pend_k);
         else pair_step_full<1>(pa, tau_p, pend_k);
 #ifdef PAIR_STAMPS
-        if (tid == 0) { atomicAdd(&g_pair_stamps[8], 1ull); atomicAdd(&g_pair_stamps[9], 1ull); }
+        if (tid == 0) { atomicAdd(&g_pair_stamps[9], 1ull); atomicAdd(&g_pair_stamps[0], ts1 - ts0); }
 #endif
       } else {
         PairGenArgs ga{ab, sb + SL.vd, sb + SL.tau2, (ldptr)slots, (ldptr)vbuf, (ldptr)u, (ldptr)red, (ldptr)sc, prog,

@@ -247,6 +247,9 @@ def test_persistent_chase_and_resume(n, batch, give_up, form):
         assert cnt["chase_timeouts"] == 0 and cnt["chase_incomplete"] == 0, cnt
         if give_up == 0:
             assert cnt["chase_resumed"] == 0 and cnt["chase_sweeps"] == batch * (n - 2), cnt
+        elif give_up >= 100 and n < 500:
+            # (small orders: a workgroup may be through before its hundredth task -- either outcome is legitimate)
+            assert cnt["chase_resumed"] in (0, 1), cnt
         else:
             assert cnt["chase_resumed"] == 1 and cnt["chase_sweeps"] < batch * (n - 2), cnt
         # every matrix: residual and orthogonality on the device; eigenvalues of the first and last against LAPACK

@@ -19,7 +19,7 @@ coord = torch.from_numpy(np.stack([np.random.RandomState(s).rand(n_atoms, 3) * b
 solver = DeviceBatchSolver(n_atoms, B, sc.HinsenForceField())
 solver.ctx.set_two_stage(True)
 L = _hip.lib()
-L.sc_dbg_set_chase(solver.ctx.handle, 2, 0)           # persistent chase always
+L.sc_dbg_set_chase(solver.ctx.handle, 3, 0)           # persistent chase always, pair form
 buf = (C.c_ulonglong * 16)()
 solver.solve(coord)
 torch.cuda.synchronize()
@@ -30,13 +30,15 @@ torch.cuda.synchronize()
 rc = L.sc_dbg_pair_stamps(buf)
 t = solver.last_timings()
 v = [int(x) for x in buf]
-steps = max(1, v[8])
-names = ["wait+go", "loads [1]", "E right + reflector [2,3]", "column sums + u [4,5]", "E left + D products [6]", "w [7]",
-         "D update + stores", "drain + barrier [8]"]
+steps = max(1, v[9])   # the stamps cover the common steps (pair_step_full) only
+names = ["wait+go [0]", "E loads issued / B: slot reads + store drain [1]", "D loads issued, E right + reflector [2,3]",
+         "column sums + u + D image [4,5]", "E left + D products [6]", "w [7]", "D update + stores"]
 print(f"rc {rc}  N = {n_atoms} x {B}: bulge chasing {t['bulge_chasing_ms']:.1f} ms, {steps} steps ({v[9]} with both teams at work), "
       f"counters launches {solver.ctx.counter('chase_launches')} timeouts {solver.ctx.counter('chase_timeouts')}")
 tot = 0
 for k, name in enumerate(names):
-    print(f"  {name:32s} {v[k] / steps:8.0f} cycles")
+    print(f"  {name:72s} {v[k] / steps:8.0f} cycles")
     tot += v[k]
 print(f"  {'step':32s} {tot / steps:8.0f} cycles")
+print(f"  inside [1]: team A, E loads issued + vp read {v[12] / steps:.0f}; team B (thread 256): slot reads {v[10] / steps:.0f}, "
+      f"store drain {v[11] / steps:.0f}; team B, D update + stores {v[13] / steps:.0f} cycles")
