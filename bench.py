@@ -459,6 +459,11 @@ def build_rooflines(t, n, B, ncols, form="per_wavefront"):
              "stage-1 back-transformation, first product: n^2 ncols flops per matrix")
         mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
              "stage-1 back-transformation, second product: n^2 ncols flops per matrix")
+        if t.get("dc_gemm_gflop", 0) > 0:
+            mfma("dc_gemm", "k_gemm2 (D&C merge products, gathered operands)", t["dc_gemm_gflop"] * 1e9, t.get("dc_gemm_ms"),
+                 "eigenvector updates of the divide & conquer merges: 2 m n k per merge record, summed on the device (K and N "
+                 "are what the deflation leaves); dense upper bound 4/3 n^3 per matrix",
+                 {"dense_bound_flops": 4.0 / 3.0 * n3 * B, "flops_over_dense_bound": round(t["dc_gemm_gflop"] * 1e9 / (4.0 / 3.0 * n3 * B), 4)})
         if t.get("bulge_chasing_ms", 0) > 0:
             # pair form: one block set is read (team A) and one written (team B) per PAIR of tasks -- half the bytes
             bb = bulge_bytes(n) * B // (2 if form == "pair" else 1)
@@ -493,6 +498,9 @@ def build_rooflines(t, n, B, ncols, form="per_wavefront"):
                 "what": "one-stage tridiagonalisation: y = A22 v, 8 B per lower-triangle element per column",
             }
         mfma("syr2k", "k_gemm2 (SYR2K)", 2.0 / 3.0 * n3 * B, t.get("syr2k_ms"), "panel SYR2K launches: 2/3 n^3 flops per matrix")
+        if t.get("dc_gemm_gflop", 0) > 0:
+            mfma("dc_gemm", "k_gemm2 (D&C merge products, gathered operands)", t["dc_gemm_gflop"] * 1e9, t.get("dc_gemm_ms"),
+                 "eigenvector updates of the divide & conquer merges: 2 m n k per merge record, summed on the device")
         mfma("bt1_w", "k_gemm2 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"), "back-transformation, first product")
         mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
              "back-transformation, second product")

@@ -274,7 +274,9 @@ int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
 /* Summed device time (ms) of one kernel group of the most recent profiled eigensolve, by name.  Two-stage path:
  * "panel_qr", "symm" (X = A22 V), "syr2k" (trailing update), "bulge", "dia_tfactor", "dc" (tridiagonal divide & conquer),
  * "dc_gemm" (its merge GEMMs), "bt2" (stage-2 back-transformation), "bt1_w" / "bt1_update" (the two GEMMs of the stage-1
- * back-transformation).  Unknown names (or phases the last solve did not run): SC_ERR_INVALID_ARG, *ms = 0. */
+ * back-transformation).  One name is not a time: "dc_gemm_gflop" = 1e9 flops those merge GEMMs executed (2 m n k summed on
+ * the device over their records: the sizes depend on the deflation and exist nowhere else).
+ * Unknown names (or phases the last solve did not run): SC_ERR_INVALID_ARG, *ms = 0. */
 int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
 
 /* Event counters of the context since it was created (monitoring; nothing in the reference corresponds).  Names:

@@ -342,6 +342,10 @@ def _last_timings(ctx, L):
         ms = C.c_double(0.0)
         if L.sc_last_eigh_phase_ms(ctx.handle, name.encode(), C.byref(ms)) == 0 and name + "_ms" not in out:
             out[name + "_ms"] = ms.value
+    # (not a time: 1e9 flops of the D&C merge GEMMs, summed on the device from their records -- the sizes depend on deflation)
+    g = C.c_double(0.0)
+    if L.sc_last_eigh_phase_ms(ctx.handle, b"dc_gemm_gflop", C.byref(g)) == 0:
+        out["dc_gemm_gflop"] = g.value
     return out
 
 

@@ -88,6 +88,35 @@ def test_structured(sc, kind):
     assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-11
 
 
+@pytest.mark.parametrize("glue", [1e-4, 1e-8, 1e-10, 1e-12])
+def test_glued_wilkinson_clustered_poles(sc, glue):
+    """
+    Clustered but NOT deflated poles in the secular equation: copies of the Wilkinson matrix W21+ glued
+    by a small off-diagonal entry have eigenvalue clusters of width ~ glue -- the merges of the divide & conquer meet
+    poles that are 1e-4 ... 1e-12 apart, too far to deflate, close enough to make a step-size stopping rule dangerous.
+    Eigenvalues against LAPACK to a few ulps of the norm, eigenvectors by residual and orthogonality.
+    """
+    m, copies = 21, 16
+    d = np.tile(np.abs(np.arange(m) - m // 2).astype(float), copies)
+    e = np.ones(m * copies - 1)
+    e[m - 1:: m] = glue
+    n = m * copies
+    a = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    w, v = sc.nma.eigh(a)
+    w_ref = np.linalg.eigvalsh(a)
+    norm = np.abs(w_ref).max()
+    assert np.abs(w - w_ref).max() <= 5e-14 * norm, np.abs(w - w_ref).max() / norm
+    assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-12 * norm
+    assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-12
+    # a graded spectrum through a random rotation: poles over fifteen orders of magnitude in one merge
+    rs = np.random.RandomState(3)
+    q, _ = np.linalg.qr(rs.randn(400, 400))
+    g = (q * np.logspace(-15, 0, 400)) @ q.T
+    g = 0.5 * (g + g.T)
+    wg = sc.nma.eigh(g, eigenvectors=False)
+    assert np.abs(wg - np.linalg.eigvalsh(g)).max() <= 5e-14
+
+
 # ---- the reference's eigen goldens ------------------------------------------------------------------
 
 @pytest.mark.parametrize("cutoff", [4, 7])
