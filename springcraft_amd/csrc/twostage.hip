@@ -535,10 +535,11 @@ __device__ __forceinline__ double wave_reduce8(const double (&v)[8]) {
   return r;
 }
 
-template <int RU, int CU>
-__global__ __launch_bounds__(1024) void k_panel_wg(double* __restrict__ a_all, long long stride_a,
+template <int RU, int CU, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_panel_wg(double* __restrict__ a_all, long long stride_a,
                                                    double* __restrict__ tri_all, TriLayout TL,
                                                    double* __restrict__ sb_all, SbLayout SL, int j0) {
+  constexpr int kWgThreads = NT, kWgWaves = NT / 64;   // (shadow the file-level constants: NT threads per panel)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* red = sm;                               // [2][kWgWaves][8] wave partials of the per-column sums (by column parity)
   double* piv = red + 2 * kWgWaves * 8;           // [2][8]          pivot row of the inner block
@@ -2884,7 +2885,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // (one workgroup per matrix while the panel is short enough for its rows to sit in the registers of 1024 threads --
     // also for a single matrix: N = 512 two-stage 45 -> 37 ms; SPRINGCRAFT_QR_WG = 0 keeps the chunked launches)
     static const int env_wg = [] { const char* e = getenv("SPRINGCRAFT_QR_WG"); return e ? atoi(e) : -1; }();
+    // (round 4: panels of 4097 .. 6144 rows -- the first 29 of n = 6000 -- by 512 threads with up to 12 rows each: twice
+    // the registers per thread; SPRINGCRAFT_QR_WG = 1 keeps them on the chunked launches)
     const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0;
+    const bool use_wg512 = nr == kB && !use_wg && m <= 12 * 512 && env_wg != 0 && env_wg != 1 && batch >= 4;
     if (use_wg) {
       const size_t lds_wg = sizeof(double) * (size_t)(2 * kWgWaves * 8 + 16 + 8 + 8 * kB + kWgWaves * kB * 8);
       const int ru = (m + kWgThreads - 1) / kWgThreads;
@@ -2893,6 +2897,13 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       else if (ru == 2) hipLaunchKernelGGL((k_panel_wg<2, 8>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
       else if (ru == 3) hipLaunchKernelGGL((k_panel_wg<3, 4>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
       else hipLaunchKernelGGL((k_panel_wg<4, 2>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+    } else if (use_wg512) {
+      constexpr int kW = 512 / 64;
+      const size_t lds_wg = sizeof(double) * (size_t)(2 * kW * 8 + 16 + 8 + 8 * kB + kW * kB * 8);
+      const int ru = (m + 511) / 512;
+      const dim3 g1((unsigned)nb), b1(512u);
+      if (ru <= 10) hipLaunchKernelGGL((k_panel_wg<10, 1, 512>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
+      else hipLaunchKernelGGL((k_panel_wg<12, 1, 512>), g1, b1, lds_wg, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0);
     } else if (nr == kB && blocked_qr) {
       // blocked panel: inner blocks of 8 columns, their reflectors applied to the rest of the panel at once
       hipLaunchKernelGGL(k_panel_qr, qgrid, dim3(256), lds_qr_blk, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0, 0, nr, kIb);
