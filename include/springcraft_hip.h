@@ -255,8 +255,8 @@ int sc_dev_eigh_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, double* 
 int sc_dev_eigh_range_f64(sc_ctx* ctx, double* d_a, int64_t n, int64_t batch, int64_t il, int64_t iu,
                           double* d_w, double* d_v);
 
-/* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when n >= 1024 and
- * batch * n^2 >= 5e7 + 6.7e3 n, else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the
+/* Tridiagonalisation path of the eigensolver: -1 automatic (default: two-stage when n >= 512 and
+ * batch * n^2 >= max(2e7, 1e4 n), else one-stage), 0 always one-stage, 1 two-stage whenever n >= 256.  Both give the
  * same eigenpairs to rounding (|dw| ~ 1e-14 |w|max); the choice only affects speed. */
 int sc_ctx_set_two_stage(sc_ctx* ctx, int mode);
 

@@ -2888,7 +2888,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // (round 4: panels of 4097 .. 6144 rows -- the first 29 of n = 6000 -- by 512 threads with up to 12 rows each: twice
     // the registers per thread; SPRINGCRAFT_QR_WG = 1 keeps them on the chunked launches)
     const bool use_wg = nr == kB && m <= 4 * kWgThreads && env_wg != 0;
-    const bool use_wg512 = nr == kB && !use_wg && m <= 12 * 512 && env_wg != 0 && env_wg != 1 && batch >= 4;
+    // (not for a few matrices: one workgroup streams its panel at the rate of ONE CU -- a single N = 2000 structure's
+    // panel QRs take 70 instead of 52 ms that way)
+    const bool use_wg512 = nr == kB && !use_wg && m <= 12 * 512 && env_wg != 0 && env_wg != 1 && nb >= 4;
     if (use_wg) {
       const size_t lds_wg = sizeof(double) * (size_t)(2 * kWgWaves * 8 + 16 + 8 + 8 * kB + kWgWaves * kB * 8);
       const int ru = (m + kWgThreads - 1) / kWgThreads;

@@ -25,5 +25,5 @@ for n_atoms, B in ((2000, 1), (2000, 2), (2000, 3), (2000, 4), (1000, 1), (1000,
         r = subprocess.run([sys.executable, "-c", code, str(n_atoms), str(B), str(two)], capture_output=True, text=True, timeout=300)
         row.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "fail")
     n = 3 * n_atoms
-    auto = "two" if (n >= 1024 and B * n * n >= 5.0e7 + 6.7e3 * n) else "one"   # eigh.hip:two_stage_for
+    auto = "two" if (n >= 512 and B * n * n >= max(2.0e7, 1.0e4 * n)) else "one"   # eigh.hip:two_stage_for
     print(f"N={n_atoms:5d} n={n:5d} B={B:3d}: one-stage {row[0]:>8s} ms   two-stage {row[1]:>8s} ms   (automatic: {auto}-stage)", flush=True)

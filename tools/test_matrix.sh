@@ -2,7 +2,10 @@
 # The eigensolver tests under every switch that selects an alternative code path (on the GPU box):  bash tools/test_matrix.sh
 set -u
 T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py"
-run() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q 2>&1 | tail -1; }
+# (two halves, a gpurun call is limited to 20 minutes:  bash tools/test_matrix.sh 1 | 2; no argument: everything)
+HALF=${1:-0}
+K=0
+run() { K=$((K+1)); if [ $HALF -ne 0 ] && [ $((K % 2)) -ne $((HALF % 2)) ]; then return; fi; echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q 2>&1 | tail -1; }
 run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=1 SPRINGCRAFT_STAGE1_STREAMS=1
 run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3
 run SPRINGCRAFT_BULGE_PERSISTENT=2
@@ -16,3 +19,8 @@ run SPRINGCRAFT_SYMM_SPLIT=4 SPRINGCRAFT_BT2_WAVE=1
 run SPRINGCRAFT_BT2_WAVE=0
 run SPRINGCRAFT_PANEL_PAIRS=0
 run SPRINGCRAFT_QR_WG=0
+run SPRINGCRAFT_QR_WG=1
+run SPRINGCRAFT_BULGE_PERSISTENT=2 SPRINGCRAFT_BULGE_PAIR=2
+run SPRINGCRAFT_BULGE_PAIR=0
+run SPRINGCRAFT_TWO_STAGE=1
+run SPRINGCRAFT_TWO_STAGE=0
