@@ -1103,16 +1103,37 @@ __global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_a
 // per XCD, [10..12] (matrix, sweep, task) of the wait that timed out, [16..23] sweeps finished per XCD.
 constexpr int kChaseCtlInts = 32;
 
+// Early hand-off (round 4).  Task (s, k) reads three things from sweep s - 1: the blocks task (s - 1, k) has left --
+// all its rows but the last --, and from task (s - 1, k + 1) its last row: the entry beta (what remains of the column that
+// task annihilated) in the off-diagonal block and the row of the diagonal block.  The right update of the off-diagonal
+// block and the new reflector only need beta, which task (s - 1, k + 1) knows as soon as it has generated ITS reflector --
+// two thirds of a task before its stores have drained.  So a task publishes (beta, position) in a 16-byte record right
+// there, its successor in the next sweep starts when task (s - 1, k) is complete and that record is in, loads its blocks
+// and runs the first half of its work, and only then waits for (s - 1, k + 1) to be complete, fetches the last row of its
+// diagonal block, and stores.  Nothing is stored before that second wait, so the order of the writes to the band is the
+// one of the plain dependence.  The dependent chain of a latency-bound chase -- one task per link -- shortens by the
+// loads and the first half of the arithmetic (profiles/r04_bulge_sweep.txt).
+// Records: a ring of kEarlyRing per sweep, slot k mod kEarlyRing holds {beta of task k, k + 1}; written and read as ONE
+// 16-byte access.  A reader that finds a later tag knows that its task (s - 1, k + 1) is long complete and takes the
+// entry from the band instead.
+constexpr int kEarlyRing = 8;
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16(void* p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ v4i ld16_l2(const void* p) {
+  v4i r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
 
 __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W, int nxcd,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
-                                                     int* __restrict__ ctl, int give_up_after) {
+                                                     int* __restrict__ ctl, int give_up_after, v4i* __restrict__ early) {
   constexpr int LD = kB + 1;
   __shared__ double E[kB * LD];
   double* D = E;
   __shared__ double vbuf[2][kB], u[kB], red[4 * kB];
-  __shared__ double s_tau, s_beta;
-  __shared__ int s_go, s_claim;
+  __shared__ double s_tau, s_beta, s_beta_in;
+  __shared__ int s_go, s_claim, s_mode;
 
   const int n = SL.n;
   const int tid = threadIdx.x;
@@ -1157,36 +1178,79 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
       for (int k = 0; k < len; ++k) {
         double* vp = vbuf[(k + 1) & 1];   // reflector of task k - 1 of this sweep
         double* vn = vbuf[k & 1];
-        // ---- wait for sweep s - 1
+        // ---- wait for sweep s - 1.  With a task (s - 1, k + 1) to wait for (early hand-off, see above): task (s - 1, k)
+        // complete AND either (s - 1, k + 1) complete too (mode 2: everything is in the band) or its record in (mode 1:
+        // beta from the record, the last row of the diagonal block after the second wait).  Else (mode 0): all of sweep
+        // s - 1 that touches these rows is complete.
+        const bool early_task = early != nullptr && s > 0 && k + 1 < len_prev;
         if (tid == 0) {
           // (the stop flag and the predecessor's progress are requested TOGETHER: one L2 round trip, ~0.7 us, per task on
           // the sweep-to-sweep critical path instead of two; while waiting, the flag is looked at every 16th poll only)
-          const int need = s > 0 ? min(k + 2, len_prev) : 0;
+          const int need = s > 0 ? min(k + (early_task ? 1 : 2), len_prev) : 0;
           const int stop0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           int have = s > 0 ? __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
           int go = stop0 ? 0 : 1;
-          if (go) {
-            long spins = 0;
-            while (have < need) {
-              // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
-              ++spins;
-              if (spins > (1L << 21) ||
-                  ((spins & 15) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                  ctl[10] = b; ctl[11] = s; ctl[12] = k;
-                }
-                __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                go = 0;
+          int mode = 0;
+          double beta_in = 0.0;
+          const v4i* rec = early_task ? early + ((size_t)b * n + s - 1) * kEarlyRing + ((k + 1) & (kEarlyRing - 1)) : nullptr;
+          long spins = 0;
+          while (go) {
+            if (have >= need) {
+              if (!early_task) break;
+              if (have >= k + 2) { mode = 2; break; }
+              const v4i r = ld16_l2(rec);
+              if (r.z == k + 2) {
+                mode = 1;
+                beta_in = __longlong_as_double((long long)(((unsigned long long)(unsigned)r.y << 32) | (unsigned)r.x));
                 break;
               }
-              __builtin_amdgcn_s_sleep(1);
-              have = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
+            ++spins;
+            if (spins > (1L << 21) ||
+                ((spins & 15) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                ctl[10] = b; ctl[11] = s; ctl[12] = k;
+              }
+              __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              go = 0;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            have = __hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           s_go = go;
+          s_mode = mode;
+          s_beta_in = beta_in;
         }
         __syncthreads();
         if (!s_go) return;
+        const int mode = s_mode;   // 1: the last row of both blocks is not in the band yet
+        // second wait of a task that started on the record (mode 1): task (s - 1, k + 1) complete, then the last row of
+        // the diagonal block.  Nothing of this task has been stored before.
+#define CHASE_SECOND_WAIT()                                                                                       \
+        if (mode == 1) {                                                                                          \
+          if (tid == 0) {                                                                                         \
+            int go = 1;                                                                                           \
+            long spins = 0;                                                                                       \
+            while (__hip_atomic_load(prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 2) {         \
+              ++spins;                                                                                            \
+              if (spins > (1L << 21) ||                                                                           \
+                  ((spins & 15) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {    \
+                if (!__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {                        \
+                  ctl[10] = b; ctl[11] = s; ctl[12] = k;                                                          \
+                }                                                                                                 \
+                __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                           \
+                go = 0;                                                                                           \
+                break;                                                                                            \
+              }                                                                                                   \
+              __builtin_amdgcn_s_sleep(1);                                                                        \
+            }                                                                                                     \
+            s_go = go;                                                                                            \
+          }                                                                                                       \
+          __syncthreads();                                                                                        \
+          if (!s_go) return;                                                                                      \
+        }
 
         const int r0 = s + 1 + k * kB;
         const int L = min(kB, n - r0);
@@ -1214,6 +1278,11 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) t16[c] = i < L ? t16[c] : 0.0;
+            if (mode == 1 && i == kB - 1) {   // the last row: zeros and the predecessor's beta (the band still holds the old entry)
+              const double bin = s_beta_in;
+#pragma unroll
+              for (int c = 0; c < 16; ++c) t16[c] = q * 16 + c == kB - 1 ? bin : 0.0;
+            }
           }
           {
             double a = 0.0;
@@ -1235,7 +1304,13 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             const double t2 = wave_sum((i >= 1 && i < L) ? x * x : 0.0);
             const HH h = householder(__shfl(x, 0), t2);
             vn[i] = i == 0 ? 1.0 : (i < L ? x * h.scale : 0.0);
-            if (i == 0) { s_tau = h.tau; s_beta = h.beta; }
+            if (i == 0) {
+              s_tau = h.tau; s_beta = h.beta;
+              if (early) {   // the record of this task: all its successor in sweep s + 1 needs to start on
+                const unsigned long long bb = (unsigned long long)__double_as_longlong(h.beta);
+                st16(early + ((size_t)b * n + s) * kEarlyRing + (k & (kEarlyRing - 1)), v4i{(int)(unsigned)bb, (int)(unsigned)(bb >> 32), k + 1, 0});
+              }
+            }
           }
           lds_barrier();
           {
@@ -1247,6 +1322,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           lds_barrier();
           if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
           lds_barrier();
+          CHASE_SECOND_WAIT()
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
             const int jj = q * 16 + c;
@@ -1255,19 +1331,29 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             if (i < L) ebase_k[(unsigned)((kB + i - jj) + jj * kLdab)] = e;
           }
         } else {
+          gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
           if (tid < 64) {
-            gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
             const double xr = ld_l2(col_s + (unsigned)(1 + min(tid, L - 1)));
-            const double x = tid < L ? xr : 0.0;
+            double x = tid < L ? xr : 0.0;
+            if (mode == 1 && tid == kB - 1) x = s_beta_in;   // (its last entry is task (s - 1, 1)'s beta)
             const double t2 = wave_sum(tid >= 1 ? x * x : 0.0);
             const HH h = householder(__shfl(x, 0), t2);
             vn[tid] = tid == 0 ? 1.0 : x * h.scale;
             if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
-            if (tid < L) col_s[(unsigned)(1 + tid)] = tid == 0 ? h.beta : 0.0;
           }
           lds_barrier();
+          CHASE_SECOND_WAIT()
+          if (tid < L) col_s[(unsigned)(1 + tid)] = tid == 0 ? s_beta : 0.0;
         }
-        // ---- diagonal block
+#undef CHASE_SECOND_WAIT
+        // ---- diagonal block (after the second wait its last row is in the band)
+        if (mode == 1 && i == kB - 1) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const int jc = q * 16 + c;
+            d16[c] = ld_l2(colbase_k + (unsigned)((kB - 1 - jc) + jc * kLdab));
+          }
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const int jj = q * 16 + c;
@@ -3045,11 +3131,17 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
         const size_t prog_bytes = align_up((size_t)batch * n * sizeof(int), 256);
         const size_t next_bytes = align_up((size_t)batch * sizeof(int), 256);
         const size_t ctl_bytes = align_up(kChaseCtlInts * sizeof(int), 256);
-        SC_TRY(sc_reserve_dc_aux(ctx, prog_bytes + next_bytes + ctl_bytes));
+        // early hand-off records of k_bulge_chase (16 B x kEarlyRing per sweep; zeroed with the counters: a stale tag of
+        // the previous solve would pass for this one's)
+        static const bool no_early = getenv("SPRINGCRAFT_BULGE_NO_EARLY") != nullptr;
+        const size_t early_bytes = (pair || no_early) ? 0 : align_up((size_t)batch * n * kEarlyRing * sizeof(v4i), 256);
+        SC_TRY(sc_reserve_dc_aux(ctx, prog_bytes + next_bytes + ctl_bytes + early_bytes));
         int* d_prog = reinterpret_cast<int*>(ctx->dc_aux);
         int* d_next = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes);
         int* d_ctl = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes + next_bytes);
-        SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + next_bytes + ctl_bytes, st));
+        v4i* d_early = early_bytes ? reinterpret_cast<v4i*>(reinterpret_cast<char*>(ctx->dc_aux) + prog_bytes + next_bytes + ctl_bytes)
+                                   : nullptr;
+        SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, prog_bytes + next_bytes + ctl_bytes + early_bytes, st));
         // the dispatcher deals workgroups round-robin over the XCDs, so 8 x (workgroups one XCD needs) gives every XCD
         // its share; the kernel does not rely on it (a short-changed XCD is just slower, see the kernel's header)
         const int grid = nxcd * std::min(slots_per_xcd, mpx * W);
@@ -3060,7 +3152,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                              ctx->chase_give_up);
         else
           hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
-                             d_next, d_ctl, ctx->chase_give_up);
+                             d_next, d_ctl, ctx->chase_give_up, d_early);
         const hipError_t le = hipGetLastError();
         t_bulge.stop();
         if (le == hipSuccess) {
