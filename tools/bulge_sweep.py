@@ -20,7 +20,7 @@ solver.solve(coord); torch.cuda.synchronize()
 t = solver.last_timings()
 print(f"{t['bulge_chasing_ms']:.1f}")
 '''
-MODES = (("pair", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "1"}),
+MODES = (("pair", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "2"}),
          ("sweep/wg", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "0"}),
          ("per-wavefront", {"SPRINGCRAFT_BULGE_PERSISTENT": "0"}))
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"

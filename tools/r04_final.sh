@@ -2,10 +2,10 @@
 # Round-4 evidence on one GPU box, in parts (a gpurun call is limited to 20 minutes):
 #   bash tools/r04_final.sh a   the -m gpu suite with durations, the four bench lines (C3 with the CPU baseline), latencies
 #   bash tools/r04_final.sh b   rocprofv3 kernel statistics of the default bench command, PMC passes of k_bulge_pair at the
-#                               benchmarked batch, per-step stamps of the pair chase (-DPAIR_STAMPS build), the chase sweep
+#                               benchmarked batch, per-step stamps of the pair chase (-DPAIR_STAMPS build)
 #   bash tools/r04_final.sh c   two-rank shared-GPU rehearsal WITH the CPU baseline next to the one-rank line, the one- /
 #                               two-stage crossover
-#   bash tools/r04_final.sh d1 | d2   the test matrix (tools/test_matrix.sh), in two halves
+#   bash tools/r04_final.sh d1 | d2   the chase sweep (d1) and the test matrix (tools/test_matrix.sh), in two halves
 # Everything lands in gpurun_out/r04_final/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -34,8 +34,6 @@ elif [ $part = b ]; then
   cp -r gpurun_out/pmc_r04_bulge $OUT/ 2>/dev/null
   SPRINGCRAFT_HIP_LIB=$ROOT/springcraft_amd/libspringcraft_hip_stamps.so timeout -k 10 200 python tools/pair_stamps.py 2000 64 > $OUT/pair_stamps.txt 2>&1
   grep -v amdgpu.ids $OUT/pair_stamps.txt
-  timeout -k 10 700 python tools/bulge_sweep.py > $OUT/bulge_sweep.txt 2>&1
-  cat $OUT/bulge_sweep.txt
 elif [ $part = c ]; then
   # the same (small) workload on one rank and on two ranks sharing the GPU: the CPU baseline must come out the same
   timeout -k 10 300 python bench.py --structures-per-gpu 8 --steps 2 --warmup 1 > $OUT/rehearsal_1rank.json 2> $OUT/rehearsal_1rank.err || { tail -5 $OUT/rehearsal_1rank.err; exit 1; }
@@ -52,6 +50,8 @@ PY
   timeout -k 10 500 python tools/crossover.py > $OUT/two_stage_crossover.txt 2>&1
   cat $OUT/two_stage_crossover.txt
 elif [ $part = d1 ]; then
+  timeout -k 10 500 python tools/bulge_sweep.py > $OUT/bulge_sweep.txt 2>&1
+  cat $OUT/bulge_sweep.txt
   bash tools/test_matrix.sh 1 > $OUT/test_matrix_1.txt 2>&1
   cat $OUT/test_matrix_1.txt
 else
