@@ -286,3 +286,38 @@ def test_chase_by_size_rule_counts(sc):
     assert s.ctx.counter("chase_launches") == 3 and s.ctx.counter("chase_sweeps") == 3 * B * (3 * n_atoms - 2)
     assert s.ctx.counter("chase_timeouts") == 0 and s.ctx.counter("chase_resumed") == 0
     assert s.ctx.counter("chase_xcd_min") >= 1
+
+
+def test_pair_chase_by_size_rule(sc):
+    """
+    The automatic rule on a batch that is bound by bytes (batch * n / 128 > 1100, at least 8 matrices): the chase runs in
+    the pair form (k_bulge_pair: two sweeps per workgroup through LDS), completes every sweep itself, and the
+    eigenpairs of every member are right.
+    """
+    import os
+
+    import torch
+
+    from springcraft_amd.batch import DeviceBatchSolver
+
+    if os.environ.get("SPRINGCRAFT_BULGE_PERSISTENT") is not None or os.environ.get("SPRINGCRAFT_BULGE_PAIR") is not None:
+        pytest.skip("the size rule is overridden (tools/test_matrix.sh)")
+    n_atoms, B = 342, 144                      # n = 1026, batch * n / 128 = 1154
+    coords_np = np.stack([synthetic_coord(n_atoms, 500 + s) for s in range(B)])
+    s = DeviceBatchSolver(n_atoms, B, sc.HinsenForceField(13.0))
+    s.ctx.set_two_stage(True)
+    w, v = s.solve(torch.from_numpy(coords_np).cuda())
+    s.finish()
+    assert s.ctx.counter("chase_pair_launches") == 1 and s.ctx.counter("chase_launches") == 1
+    assert s.ctx.counter("chase_sweeps") == B * (3 * n_atoms - 2)
+    assert s.ctx.counter("chase_timeouts") == 0 and s.ctx.counter("chase_resumed") == 0
+    eye = torch.eye(3 * n_atoms, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        assert float((v[b] @ v[b].T - eye).abs().max()) <= 1e-11, b
+    for b in (0, 77, B - 1):
+        h, _ = orc.compute_hessian(coords_np[b], orc.hinsen_ff(13.0))
+        w_ref = np.linalg.eigvalsh(h)
+        wb, vb = w[b].cpu().numpy(), v[b].cpu().numpy()
+        assert np.abs(wb - w_ref).max() <= 1e-11 * np.abs(w_ref).max(), b
+        assert np.abs(h @ vb.T - vb.T * wb[None, :]).max() <= 1e-10 * np.abs(w_ref).max(), b
+

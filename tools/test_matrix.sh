@@ -23,4 +23,3 @@ run SPRINGCRAFT_QR_WG=1
 run SPRINGCRAFT_BULGE_PERSISTENT=2 SPRINGCRAFT_BULGE_PAIR=2
 run SPRINGCRAFT_BULGE_PAIR=0
 run SPRINGCRAFT_TWO_STAGE=1
-run SPRINGCRAFT_TWO_STAGE=0
