@@ -260,6 +260,73 @@ def test_user_defined_force_fields_in_one_padded_solve(sc, dim):
         assert np.abs(wk - w_ref).max() <= 1e-10 * np.abs(w_ref).max(), k
 
 
+def test_user_defined_force_fields_edge_cases(sc):
+    """
+    The batched host-callback path at its edges: a structure without any contact (empty pair list inside a batch: its slot
+    is the zero matrix), a whole batch without contacts (k = 0: no scatter launch at all), and a user-defined force field
+    that also overrides the contact patches (`contact_shutdown` / `contact_pair_off` / `contact_pair_on`, forcefield.py:96-114;
+    applied in that order, interaction.py:193-213) -- against the oracle, pair lists included.
+    """
+    import torch
+
+    from springcraft_amd.batch import RaggedBatchSolver
+
+    class Sparse(sc.ForceField):            # nothing within 0.5 A of anything
+        def force_constant(self, atom_i, atom_j, sq_distance):
+            return np.full(len(atom_i), 3.0)
+
+        @property
+        def cutoff_distance(self):
+            return 0.5
+
+    class Patched(sc.ForceField):
+        def force_constant(self, atom_i, atom_j, sq_distance):
+            return 2.0 + 0.1 * np.minimum(atom_i, atom_j)
+
+        @property
+        def cutoff_distance(self):
+            return 8.0
+
+        @property
+        def contact_shutdown(self):
+            return np.array([4, 17])
+
+        @property
+        def contact_pair_off(self):
+            return np.array([[0, 1], [2, 3]])
+
+        @property
+        def contact_pair_on(self):
+            return np.array([[5, 40], [4, 30]])      # (4, 30): switched on although atom 4 is shut down
+
+    sizes = [45, 50, 38]
+    coords = [synthetic_coord(n, 90 + k) for k, n in enumerate(sizes)]
+    ffs = [Sparse(), Patched(), Sparse()]
+    s = RaggedBatchSolver(sizes, ffs, dim=1)
+    packed = _packed(coords)
+    per = s.pairs(packed)
+    assert len(per[0][0]) == 0 and len(per[2][0]) == 0
+    patched_o = orc.OracleFF(lambda i, j, d2: 2.0 + 0.1 * np.minimum(i, j), 8.0, contact_shutdown=[4, 17],
+                             contact_pair_off=[[0, 1], [2, 3]], contact_pair_on=[[5, 40], [4, 30]])
+    k_ref, pairs_ref = orc.compute_kirchhoff(coords[1], patched_o)
+    assert np.array_equal(per[1][0], pairs_ref)
+    s.assemble(packed)
+    torch.cuda.synchronize()
+    m_all = s.matrix.cpu().numpy()
+    assert np.array_equal(m_all[1, :50, :50], k_ref)
+    assert np.all(m_all[0, :45, :45] == 0) and np.all(m_all[2, :38, :38] == 0)
+    w, _ = s.solve(packed)
+    res = s.results()
+    assert np.abs(res[0][0].cpu().numpy()).max() == 0.0
+    w_ref = np.linalg.eigvalsh(k_ref)
+    assert np.abs(res[1][0].cpu().numpy() - w_ref).max() <= 1e-10 * np.abs(w_ref).max()
+    # a whole batch without a single contact
+    s0 = RaggedBatchSolver([20, 31], Sparse(), dim=3)
+    s0.solve(_packed([synthetic_coord(20, 1), synthetic_coord(31, 2)]))
+    for wk, _ in s0.results():
+        assert np.abs(wk.cpu().numpy()).max() == 0.0
+
+
 def test_errors(sc):
     from springcraft_amd.batch import RaggedBatchSolver
 
