@@ -1418,10 +1418,16 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
 //   D'(i, j) = D_k(i + 1, j + 1),  D'(63, j) = E_{k+1}(0, j + 1),  D'(63, 63) = D_{k+1}(0, 0)
 // so every element A leaves behind is consumed by exactly one task of B -- except the entries A has just annihilated
 // (E_k(1.., 0)), which no block of sweep sB covers, and the corner D_0(0, 0) of A's first block, which has no task of B
-// above it: A stores those to the band itself.  tools/models/bulge_pair_model.py is the NumPy model of this data flow.  The column sums a task needs (z = E^T v and
-// the strictly-lower half of p = D v) read an LDS image of the block: for A that is its slot, for B the slot it has just
-// emptied.  Both teams execute ONE instruction stream with the same nine workgroup barriers per step; what differs is
-// where blocks come from (A: memory through the L2, B: LDS) and go to (A: LDS, B: memory).
+// above it: A stores those to the band itself.  tools/models/bulge_pair_model.py is the NumPy model of this data flow
+// (tests/test_bulge_pair_model.py runs it on the CPU).  The column sums a task needs (z = E^T v and the strictly-lower
+// half of p = D v) read an LDS image of the block: for A that is its slot, for B the slot it has just emptied.
+//
+// Both teams keep ONE barrier schedule -- eight workgroup barriers per step, [0] .. [7] -- and differ in where blocks come
+// from (A: memory through the L2, B: LDS) and go to (A: LDS, B: memory).  A step is either the common one (both teams on
+// full 64-row blocks, neither at a sweep start: pair_step_full<TEAM>, one instruction stream per team without masks,
+// clamps or case distinctions) or the general one (pair_step_general: every case, out of line so that its registers are
+// not charged to the common step).  B's store drain and its publish sit behind the NEXT step's barrier [1], where team
+// A waits for its E loads anyway; A's D loads are issued behind that barrier and land during steps (2)-(4).
 //
 // Dependences across workgroups are those of k_bulge_chase: pairs are CLAIMED in order (so the owner of sweep sA - 1 is
 // running or done), A's task k starts when progress[sA - 1] >= k + 2, B publishes progress[sB] after its stores have
