@@ -32,6 +32,7 @@ elif [ $part = b ]; then
   head -8 $OUT/rocprofv3_kernel_stats_bench.csv
   bash tools/pmc_kernel.sh k_bulge_pair r04_bulge || exit 1
   cp -r gpurun_out/pmc_r04_bulge $OUT/ 2>/dev/null
+  [ -f $ROOT/springcraft_amd/libspringcraft_hip_stamps.so ] || bash tools/build_stamps_lib.sh > /dev/null   # (hipcc cross-compiles: also before the call)
   SPRINGCRAFT_HIP_LIB=$ROOT/springcraft_amd/libspringcraft_hip_stamps.so timeout -k 10 200 python tools/pair_stamps.py 2000 64 > $OUT/pair_stamps.txt 2>&1
   grep -v amdgpu.ids $OUT/pair_stamps.txt
 elif [ $part = c ]; then
