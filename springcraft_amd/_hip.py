@@ -8,6 +8,7 @@ shared library is missing, or no gfx950 device is visible, every compute entry p
 
 import ctypes as C
 import os
+import warnings
 from os.path import abspath, dirname, exists, join
 
 import numpy as np
@@ -262,15 +263,18 @@ class Context:
         be lost with it -- the reference would have raised LinAlgError at nma.py:61 -- so it is turned into a warning.
         """
         if self._h is not None and self._h.value:
-            rc = self._L.sc_ctx_synchronize(self._h)
-            if rc == SC_ERR_NOCONV:
-                import warnings
-
-                msg = self._L.sc_last_error(self._h)
-                warnings.warn("springcraft_amd context closed with an unreported solver failure: "
-                              + (msg.decode() if msg else "Eigenvalues did not converge"), RuntimeWarning, stacklevel=2)
-            self._L.sc_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+            try:
+                rc = self._L.sc_ctx_synchronize(self._h)
+                if rc != SC_OK:
+                    msg = self._L.sc_last_error(self._h)
+                    what = ("an unreported solver failure" if rc == SC_ERR_NOCONV
+                            else f"an unreported error (status {rc})")
+                    warnings.warn(f"springcraft_amd context closed with {what}: "
+                                  + (msg.decode() if msg else "Eigenvalues did not converge"), RuntimeWarning, stacklevel=2)
+            finally:
+                # (the handle is released whatever the warning machinery does, e.g. at interpreter shutdown)
+                self._L.sc_ctx_destroy(self._h)
+                self._h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -60,6 +60,12 @@ struct sc_ctx {
   int chase_ok = -1;
   int chase_mode = -1, chase_give_up = 0;
   int chase_form = -1;   // debug entry: 1 = pair form, 0 = one sweep per workgroup, -1 = by size
+  // XCDs of this device as a probe launch saw them (distinct XCC_ID values; 0 = not probed yet), and whether
+  // k_bulge_pair's dynamic LDS size has been raised on THIS context's device (-1 = not tried, 0 = refused, 1 = set):
+  // the attribute is per device, a process may own contexts on several
+  int nxcd = 0;
+  int pair_attr = -1;
+  long long cnt_pair_fallbacks = 0;   // pair launches that were refused and re-issued as k_bulge_chase
   // event counters since the context was created (sc_ctx_get_counter)
   long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
             cnt_chase_sweeps = 0, cnt_stepwise_chases = 0, cnt_pair_launches = 0;

@@ -72,6 +72,32 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- XCDs of the device, counted by a probe launch (once per context): every workgroup ORs the bit of the XCC_ID it
+// runs on into a mask.  8 x CUs workgroups of one wave: the dispatcher deals consecutive workgroups round-robin over
+// the XCDs, so every XCD that exists is seen.  (num_cus / 32 holds for MI350 / MI355 and their partitions only.)
+__global__ void k_xcd_probe(unsigned* mask) {
+  unsigned id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  if (threadIdx.x == 0) atomicOr(mask, 1u << (id & 15u));
+}
+int probe_xcd_count(sc_ctx* ctx, hipStream_t st) {
+  SC_TRY(sc_reserve_dc_aux(ctx, 256));
+  unsigned* d_mask = reinterpret_cast<unsigned*>(ctx->dc_aux);
+  SC_HIP(ctx, hipMemsetAsync(d_mask, 0, sizeof(unsigned), st));
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  hipLaunchKernelGGL(k_xcd_probe, dim3((unsigned)(8 * cus)), dim3(64), 0, st, d_mask);
+  SC_HIP(ctx, hipGetLastError());
+  unsigned h_mask = 0;
+  SC_HIP(ctx, hipMemcpyAsync(&h_mask, d_mask, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  SC_HIP(ctx, hipStreamSynchronize(st));
+  int count = 0, top = 0;
+  for (int b = 0; b < 16; ++b)
+    if (h_mask >> b & 1u) { ++count; top = b + 1; }
+  // the kernels bind matrix b to XCD b mod nxcd by XCC_ID value: ids must be 0 .. count - 1 (they are on every part seen)
+  ctx->nxcd = (count >= 1 && count == top) ? std::min(count, 8) : 1;
+  return SC_OK;
+}
+
 // ================================================================================================================
 // Stage 1: panel QR.  Panel = A[r0 : n, j0 : j0 + kB] (m x kB, column-major, ld n).  Launch j (0 .. nr):
 //   (a) j >= 1: finish reflector j-1 from the partial results of launch j-1 (tail Gram row, pivot row) and apply it
@@ -3104,21 +3130,29 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // matrix chases 1.6 x faster with its ~188 tasks per wavefront spread over the whole chip (411 vs 676 ms)
     static const bool use_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return !e || atoi(e) != 0; }();
     static const int force_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return e ? atoi(e) : -1; }();
-    static const bool pair_attr = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)kPairLdsBytes) == hipSuccess;
-    }();
+    if (ctx->pair_attr < 0)   // per device, hence per context: the caller made ctx->device current
+      ctx->pair_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes) == hipSuccess;
+    const bool pair_attr = ctx->pair_attr == 1;
     const long long work = (long long)batch * n / 128;
     // SPRINGCRAFT_BULGE_PAIR = 0: never the pair form, 2: the pair form for every persistent chase (tests), else by size
+    static const long long kPairWorkMax = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR_MAX"); return e ? atoll(e) : 3200LL; }();
+    // (by size only inside the measured range, profiles/r04_bulge_sweep.txt: up to 64 x 6000.  Far beyond it an XCD holds
+    // more matrices than pair workgroups fit -- one workgroup then walks all pairs of a matrix in sequence --, a regime
+    // nobody has timed: there the older rule applies)
+    const bool pair_measured = work <= kPairWorkMax;
     const bool pair = ctx->chase_form >= 0 ? (ctx->chase_form == 1 && pair_attr)
-                                           : use_pair && pair_attr && (force_pair == 2 || (work > 1100 && batch >= 8));
+                                           : use_pair && pair_attr &&
+                                                 (force_pair == 2 || (work > 1100 && batch >= 8 && pair_measured));
     const bool want_chase =
         persist == 2 || (persist == 1 && (pair || (work <= 2800 && (batch >= 8 || n <= 6144))));
     // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):
     // every further attempt could cost another bound's worth of spinning before the fallback
     // XCDs of this device: the kernels bind matrix b to XCD b mod nxcd (an MI355X in SPX mode has 8 XCDs of 32 CUs; a
     // partition of it has fewer, and a matrix bound to an XCD that is not there would never be claimed)
-    const int nxcd = std::max(1, std::min(8, ctx->num_cus / 32));
+    // (counted on the device, not derived from the CU count: ADVICE round 4)
+    if (ctx->nxcd <= 0) SC_TRY(probe_xcd_count(ctx, st));
+    const int nxcd = ctx->nxcd;
     if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
       int per_cu = 0;
       if (pair) {
@@ -3161,6 +3195,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                              d_next, d_ctl, ctx->chase_give_up, d_early);
         const hipError_t le = hipGetLastError();
         t_bulge.stop();
+        if (le != hipSuccess && pair) {
+          // a refused pair launch (e.g. the 157 KB of dynamic LDS on a device that does not grant them): this solve is
+          // finished by the per-wavefront launches below, later solves of the context leave the pair form alone
+          ctx->pair_attr = 0;
+          ++ctx->cnt_pair_fallbacks;
+        }
         if (le == hipSuccess) {
           int h_ctl[kChaseCtlInts] = {0};
           SC_HIP(ctx, hipMemcpyAsync(h_ctl, d_ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import enm_oracle as orc
 from tests.test_tabulated_gpu import atoms_of
-from tests.util import check_eigenvalues, load_csv, synthetic_coord
+from tests.util import check_eigenvalues, load_csv, oracle_patched, synthetic_coord
 
 pytestmark = pytest.mark.gpu
 
@@ -150,21 +150,29 @@ def test_patched_batch_against_oracle(sc):
         sc.PatchedForceField(sc.ParameterFreeForceField(9.0), contact_pair_on=np.array([[1, 70]]),
                              force_constants=np.array([3.0])),
     ]
+    oracles = [
+        oracle_patched(orc.invariant_ff(8.0), 90, contact_shutdown=np.array([4, 17]),
+                       contact_pair_off=np.array([[0, 1], [20, 22]]), contact_pair_on=on,
+                       force_constants=np.array([2.5, 0.5, 7.0])),
+        orc.hinsen_ff(10.0),
+        oracle_patched(orc.parameter_free_ff(9.0), 90, contact_pair_on=np.array([[1, 70]]),
+                       force_constants=np.array([3.0])),
+    ]
     masses = [rs.rand(90) + 0.5, None, rs.rand(90) + 0.5]
     s = RaggedBatchSolver(sizes, ffs, dim=3, masses=masses)
     mats = s.assemble(_packed(coords)).cpu().numpy()
     torch.cuda.synchronize()
+    refs = []
     for k, n in enumerate(sizes):
-        h_single, _ = sc.compute_hessian(coords[k], ffs[k])          # single-structure device path (oracle-checked)
+        h_single, _ = orc.compute_hessian(coords[k], oracles[k])       # the oracle's matrix of that structure
         if masses[k] is not None:
             h_single = h_single * orc.mass_weight_matrix(masses[k], 3)
+        refs.append(h_single)
         m = 3 * n
         assert np.abs(mats[k, :m, :m] - h_single).max() <= 1e-12 * np.abs(h_single).max(), k
     s.eigh()
     for k, (wk, vk) in enumerate(s.results()):
-        h_single, _ = sc.compute_hessian(coords[k], ffs[k])
-        if masses[k] is not None:
-            h_single = h_single * orc.mass_weight_matrix(masses[k], 3)
+        h_single = refs[k]
         w_ref = np.linalg.eigvalsh(h_single)
         assert np.abs(wk.cpu().numpy() - w_ref).max() <= 1e-10 * np.abs(w_ref).max(), k
 
@@ -225,7 +233,10 @@ def test_user_defined_force_fields_in_one_padded_solve(sc, dim):
     ffs[5] = sc.PatchedForceField(sc.HinsenForceField(12.0), contact_shutdown=np.array([3, 50]),
                                   contact_pair_off=np.array([[0, 1]]), contact_pair_on=np.array([[2, 90]]),
                                   force_constants=np.array([7.5]))
-    oracles[5] = None
+    # (compared with an ORACLE force field like the others, not with the product's own single-structure path)
+    oracles[5] = oracle_patched(orc.hinsen_ff(12.0), sizes[5], contact_shutdown=np.array([3, 50]),
+                                contact_pair_off=np.array([[0, 1]]), contact_pair_on=np.array([[2, 90]]),
+                                force_constants=np.array([7.5]))
     masses = [None] * 8
     masses[6] = np.random.RandomState(5).uniform(50.0, 200.0, sizes[6])
     s = RaggedBatchSolver(sizes, ffs, dim=dim, masses=masses)
@@ -239,17 +250,14 @@ def test_user_defined_force_fields_in_one_padded_solve(sc, dim):
     m_all = s.matrix.cpu().numpy()
     for k, n in enumerate(sizes):
         m = dim * n
-        if oracles[k] is None:
-            ref, pairs_ref = (sc.compute_hessian if dim == 3 else sc.compute_kirchhoff)(coords[k], ffs[k])
-        else:
-            ref, pairs_ref = (orc.compute_hessian if dim == 3 else orc.compute_kirchhoff)(coords[k], oracles[k])
+        ref, pairs_ref = (orc.compute_hessian if dim == 3 else orc.compute_kirchhoff)(coords[k], oracles[k])
         assert np.array_equal(per[k][0], pairs_ref), k
         if masses[k] is not None:
             ref = ref * orc.mass_weight_matrix(masses[k], dim)
         slot = m_all[k, :m, :m]
         if k == 2:
             assert not np.allclose(ref, ref.T)              # the asymmetric one really is
-        if masses[k] is None and oracles[k] is not None:   # (k = 5: the fused Hinsen kernel rounds d**-6 differently, <= 4 ulp)
+        if masses[k] is None and k != 5:   # (k = 5 is the host's Hinsen mirror: bit-equal too, but d**-6 is pow's business)
             off = ~np.eye(m, dtype=bool) if dim == 1 else np.kron(~np.eye(n, dtype=bool), np.ones((3, 3), dtype=bool))
             assert np.array_equal(slot[off], ref[off]), k  # same arithmetic as interaction.py:50 / :96-101
         assert np.abs(slot - ref).max() <= 1e-12 * np.abs(ref).max(), k

@@ -33,6 +33,45 @@ def synthetic_coord(n, seed, box=None):
     return rs.rand(n, 3) * box
 
 
+def forced_two_stage():
+    """None, or the tridiagonalisation path forced through SPRINGCRAFT_TWO_STAGE (tools/test_matrix.sh): False / True."""
+    import os
+
+    e = os.environ.get("SPRINGCRAFT_TWO_STAGE")
+    return None if e is None or e == "" else e != "0"
+
+
+def oracle_patched(base_ff, natoms, contact_shutdown=None, contact_pair_off=None, contact_pair_on=None,
+                   force_constants=None):
+    """
+    Oracle force field for ``PatchedForceField(base, ...)``: forcefield.py:183-226 restated on top of an oracle base force
+    field (the restatement tests/test_oracle_golden.py::test_generated_patched pins to reference-generated vectors); the
+    contact patches themselves are applied by the oracle's ``adjacency`` (interaction.py:193-213).
+    """
+    from oracle import enm_oracle as orc
+
+    cutoff = base_ff.cutoff_distance
+
+    def gamma(i, j, d2):
+        if cutoff is None:
+            fc = base_ff.gamma(i, j, d2)
+        else:
+            fc = np.zeros(len(d2))
+            m = d2 <= cutoff**2
+            fc[m] = base_ff.gamma(i[m], j[m], d2[m])
+        if contact_pair_on is not None:
+            pm = np.full((natoms, natoms), -1.0)
+            pi, pj = np.asarray(contact_pair_on).T
+            pm[pi, pj] = force_constants
+            pm[pj, pi] = force_constants
+            p = pm[i, j]
+            fc = np.where(p == -1, fc, p)
+        return fc
+
+    return orc.OracleFF(gamma, cutoff, contact_shutdown=contact_shutdown, contact_pair_off=contact_pair_off,
+                        contact_pair_on=contact_pair_on)
+
+
 def pair_digest(pairs):
     import hashlib
 
