@@ -409,7 +409,8 @@ def bulge_compulsory_bytes(n):
     return 8 * (65 * n + refl)
 
 
-CHASE_COUNTERS = ("chase_launches", "chase_pair_launches", "chase_timeouts", "chase_resumed", "stepwise_chases")
+CHASE_COUNTERS = ("chase_launches", "chase_pair_launches", "chase_timeouts", "chase_resumed", "stepwise_chases",
+                  "gemm3_launches")
 
 
 def chase_form(before, after):

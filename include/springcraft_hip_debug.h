@@ -27,6 +27,20 @@ int sc_dbg_gemm_bench(sc_ctx* ctx, int m, int n, int k, int mode, int tile, int 
 int sc_dbg_gemm_host(sc_ctx* ctx, const double* a, const double* b, double* c, int m, int n, int k, int mode, int tile,
                      int split_k, double alpha, double beta, int lower_grid);
 
+/* `count` products of ONE shape on host data through k_gemm3, the role-split persistent kernel of the short-K updates
+ * (csrc/gemm3.hip), whatever their size: a count x (m x k) column-major; b count x (k x n) column-major (layout 0,
+ * kGemmAmBk) or count x (n x k) column-major (layout 2, kGemmAmBn); c count x (m x n) column-major, in / out; C = beta C
+ * + A B with beta 0 or 1; lower: only entries on / below the diagonal are written (m == n).  Returns
+ * SC_ERR_INVALID_ARG for a shape the kernel does not take.  tests/test_gemm_gpu.py */
+int sc_dbg_gemm3_host(sc_ctx* ctx, const double* a, const double* b, double* c, int count, int m, int n, int k, int layout,
+                      int lower, double beta);
+
+/* `count` matrices of one shape on freshly allocated buffers, C += A B (lower != 0: the lower triangle, m == n), timed
+ * through k_gemm3 (kernel 3; order 0 / 1: its flat / per-XCD super-tile order) or through k_gemm2 (kernel 2) with the same
+ * records: ms_out = milliseconds per launch.  tools/gemm3_shapes.py */
+int sc_dbg_gemm3_bench(sc_ctx* ctx, int count, int m, int n, int k, int layout, int lower, int kernel, int order, int iters,
+                       double* ms_out);
+
 /* s_memtime segment sums of k_gemm2 (library built with -DGEMM_STAMPS; returns 1 otherwise): out4[0..2] =
  * shader cycles summed over waves in the prologue, the K loop and the C epilogue, out4[3] = waves counted; `reset`
  * zeroes the sums after the read.  tools/gemm_stamps.py */

@@ -399,6 +399,7 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   else if (k == "chase_pair_launches") *value = ctx->cnt_pair_launches;
   else if (k == "chase_pair_fallbacks") *value = ctx->cnt_pair_fallbacks;
   else if (k == "xcd_count") *value = ctx->nxcd;
+  else if (k == "gemm3_launches") *value = ctx->cnt_gemm3_launches;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
   else if (k == "chase_incomplete") *value = ctx->cnt_chase_incomplete;
   else if (k == "chase_resumed") *value = ctx->cnt_chase_resumed;

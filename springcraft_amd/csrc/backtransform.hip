@@ -180,12 +180,12 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       G.alpha = 1.0; G.beta = 0.0;
       G.split_stride = (long long)nbt * nbt;
       h[0 * grp + (size_t)p * batch + b] = G;
-      GemmDesc V{};   // VT_p = V T
+      GemmDesc V{};   // VT_p = -V T
       V.a = vp; V.sa_i = 1; V.sa_k = n;
       V.b = tp; V.sb_k = 1; V.sb_j = nbt;
       V.c = vtp; V.ldc = n;
       V.m = mrow; V.n = pc; V.k = pc;
-      V.alpha = 1.0; V.beta = 0.0;
+      V.alpha = -1.0; V.beta = 0.0;   // -(V T): the update below then ADDS (alpha = 1, what k_gemm3 takes); exact, bit for bit
       h[1 * grp + (size_t)p * batch + b] = V;
       GemmDesc W{};   // W1 = V^T Z[rows], split-K slices
       W.a = vp; W.sa_i = n; W.sa_k = 1;
@@ -195,12 +195,12 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
       W.alpha = 1.0; W.beta = 0.0;
       W.split_stride = (long long)nbt * ncols;
       h[2 * grp + (size_t)p * batch + b] = W;
-      GemmDesc U{};   // Z[rows] -= VT W
+      GemmDesc U{};   // Z[rows] += (-V T) W
       U.a = vtp; U.sa_i = 1; U.sa_k = n;
       U.b = bt + BL.w2; U.sb_k = 1; U.sb_j = nbt;
       U.c = d_z + (size_t)b * stride_z + cs + off; U.ldc = n;
       U.m = mrow; U.n = ncols; U.k = pc;
-      U.alpha = -1.0; U.beta = 1.0;
+      U.alpha = 1.0; U.beta = 1.0;
       h[3 * grp + (size_t)p * batch + b] = U;
       double* g12 = bt + BL.g12 + (size_t)p * kNbtT * kNbtT;
       double* tx = bt + BL.tx + (size_t)p * kNbtT * kNbtT;
@@ -247,8 +247,14 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
     if (w1s > 1) hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
     t_w.stop();
     t_u.start();
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile, 1, false, false,
-                           kGemmAmBk));
+    {
+      const int pc = std::min(nbt, n - p * nbt);
+      const bool al = (n & 1) == 0 && ((p * nbt + off) & 1) == 0 && (stride_z & 1) == 0 && (stride_a & 1) == 0 && (nbt & 1) == 0;
+      if (launch_gemm3_uniform(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, pc, kGemmAmBk, false, 1.0, 1.0,
+                               al) != SC_OK)
+        SC_TRY(launch_gemm_f64(ctx, d_descs + 3 * grp + (size_t)p * batch, batch, mrow, ncols, kGemmTile, 1, false, false,
+                               kGemmAmBk));
+    }
     t_u.stop();
   }
   SC_HIP(ctx, hipGetLastError());

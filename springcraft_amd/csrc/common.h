@@ -66,6 +66,10 @@ struct sc_ctx {
   int nxcd = 0;
   int pair_attr = -1;
   long long cnt_pair_fallbacks = 0;   // pair launches that were refused and re-issued as k_bulge_chase
+  // k_gemm3 (gemm3.hip): whether its dynamic LDS size has been raised on this context's device (-1 not tried, 0 refused,
+  // 1 set), and the launches it took
+  int gemm3_attr = -1;
+  long long cnt_gemm3_launches = 0;
   // event counters since the context was created (sc_ctx_get_counter)
   long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
             cnt_chase_sweeps = 0, cnt_stepwise_chases = 0, cnt_pair_launches = 0;

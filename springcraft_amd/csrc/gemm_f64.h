@@ -50,3 +50,11 @@ constexpr int kGemmTile = 3;
 constexpr int kGemmAmBk = 0, kGemmAkBk = 1, kGemmAmBn = 2;
 int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, int max_n, int tile,
                     int split_k = 1, bool gather = false, bool tri = false, int layout = -1, bool lower_grid = false);
+
+// The role-split persistent kernel k_gemm3 (gemm3.hip) for launches whose records share (m, n, k): returns SC_OK when it
+// took the launch, 1 when the launch is not one it takes (the caller then uses launch_gemm_f64).  alpha must be 1 and beta
+// 0 or 1 -- callers fold a sign into an operand --; aligned16: every operand pointer and leading dimension of the
+// records keeps 16-byte alignment (the host built them).  SPRINGCRAFT_GEMM3 = 0 switches it off, = 2 takes every
+// launch that qualifies whatever its size (tests).
+int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
+                         double alpha, double beta, bool aligned16);

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_panel_qr(double* __restrict__ a_all, lo
         else if (rl == prev) P[(prev - c_lo) * LD + tid] = s_beta;
         const size_t row = (size_t)r0 + rl;
         sb[SL.vw + (size_t)prev * n + row] = v;
-        sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
+        sb[SL.wv + (size_t)(kB + prev) * n + row] = -v;   // (the [W|V] panel holds -[W|V]: see the trailing update's record)
         sb[SL.xv + (size_t)(2 * kB + prev) * n + row] = v;
       }
     }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_pqr_blk_a(double* __restrict__ a_all, l
       else if (rl == prev) A[(size_t)(j0 + prev) * n + r0 + rl] = s_beta;
       const size_t row = (size_t)r0 + rl;
       sb[SL.vw + (size_t)prev * n + row] = v;
-      sb[SL.wv + (size_t)(kB + prev) * n + row] = v;
+      sb[SL.wv + (size_t)(kB + prev) * n + row] = -v;   // (the [W|V] panel holds -[W|V]: see the trailing update's record)
       sb[SL.xv + (size_t)(2 * kB + prev) * n + row] = v;
     }
     P[(prev - c0) * LD + tid] = v;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(NT) void k_panel_wg(double* __restrict__ a_all, lon
         if (ok[u]) {
           if (rl[u] >= c0) st(P + (size_t)j * n, rl[u], rl[u] > j ? v[u] : (rl[u] == j ? h.beta : x[u][jj]));
           st(sb + SL.vw + (size_t)j * n + r0, rl[u], v[u]);
-          st(sb + SL.wv + (size_t)(kB + j) * n + r0, rl[u], v[u]);
+          st(sb + SL.wv + (size_t)(kB + j) * n + r0, rl[u], -v[u]);   // (-[W|V])
           st(sb + SL.xv + (size_t)(2 * kB + j) * n + r0, rl[u], v[u]);
         }
         x[u][jj] = ok[u] ? v[u] : 0.0;
@@ -2927,14 +2927,18 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       W.c = sb + SL.vw + (size_t)vw_w * n + r0; W.ldc = n;
       W.m = m; W.n = kB; W.k = 3 * kB; W.alpha = 1.0; W.beta = 0.0;
       g[3] = W;
+      // (the [W|V] panel holds -[W|V], so that every product that subtracts -- the trailing updates, the correction of X
+      // in a pair -- has alpha = 1: the role-split kernel k_gemm3 keeps C itself in its accumulators and folds no sign;
+      // negation is exact, the results are bit for bit those of alpha = -1 on [W|V])
       W.c = sb + SL.wv + (size_t)wv_w * n + r0;
+      W.alpha = -1.0;
       g[4] = W;
       // trailing update, lower triangle: A22 -= [V|W] [W|V]^T (single panel) or the four-block form (second of a pair)
       GemmDesc R{};
       R.a = sb + SL.vw + r0; R.sa_i = 1; R.sa_k = n;
       R.b = sb + SL.wv + r0; R.sb_k = n; R.sb_j = 1;
       R.c = a22; R.ldc = n;
-      R.m = m; R.n = m; R.k = rl == 2 ? 4 * kB : 2 * kB; R.alpha = -1.0; R.beta = 1.0;
+      R.m = m; R.n = m; R.k = rl == 2 ? 4 * kB : 2 * kB; R.alpha = 1.0; R.beta = 1.0;   // b = -[W|V]
       R.lower_only = 1;
       g[5] = R;
       // first of a pair: only the next panel's 64 columns (and the band block above them) get this panel's update now
@@ -2953,7 +2957,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       Cr.a = sb + SL.vw + r0; Cr.sa_i = 1; Cr.sa_k = n;
       Cr.b = sb + SL.p2; Cr.sb_k = 1; Cr.sb_j = 2 * kB;
       Cr.c = sb + SL.xv + r0; Cr.ldc = n;
-      Cr.m = m; Cr.n = kB; Cr.k = 2 * kB; Cr.alpha = -1.0; Cr.beta = 1.0;
+      Cr.m = m; Cr.n = kB; Cr.k = 2 * kB; Cr.alpha = 1.0; Cr.beta = 1.0;   // P2 comes out negated (a = -[W1|V1])
       g[8] = Cr;
     }
   }
@@ -3066,7 +3070,10 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     if (rl == 1)
       SC_TRY(launch_gemm_f64(ctx, g + 6 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBn));
     else
-      SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
+      // (records of one launch share (m, m, K); operands start at even rows of buffers with even leading dimension n)
+      if (launch_gemm3_uniform(ctx, g + 5 * batch + lo, nb, m, m, rl == 2 ? 4 * kB : 2 * kB, kGemmAmBn, /*lower=*/true, 1.0, 1.0,
+                               /*aligned16=*/(n & 1) == 0 && (r0 & 1) == 0) != SC_OK)
+        SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
     if (timed) t_syr2k.stop();
     return SC_OK;
   };

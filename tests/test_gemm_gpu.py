@@ -87,3 +87,89 @@ def test_degenerate_sizes(gemm):
         gemm(5, 3, 17, 2, tile, beta=1.0, alpha=2.5)
         gemm(130, 1, 16, 0, tile)
         gemm(1, 130, 15, 0, tile)
+
+
+# ---- k_gemm3 (csrc/gemm3.hip): the role-split persistent kernel of the short-K updates ----------------------------------
+@pytest.fixture(scope="module")
+def gemm3():
+    from springcraft_amd import _hip
+
+    L = _hip.lib()
+    ctx = _hip.context()
+    fn = L.sc_dbg_gemm3_host
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_double]
+    fn2 = L.sc_dbg_gemm_host
+    fn2.restype = C.c_int
+    fn2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_double, C.c_double, C.c_int]
+
+    def run(count, m, n, k, layout, lower=0, beta=1.0, seed=0, against_gemm2=True):
+        rs = np.random.RandomState(seed)
+        A = rs.uniform(-1, 1, (count, m, k))
+        B = rs.uniform(-1, 1, (count, k, n))
+        C0 = rs.uniform(-1, 1, (count, m, n))
+        # per matrix column-major: A (i, kk) at kk*m + i; B (kk, j) at j*k + kk (layout 0) or kk*n + j (layout 2)
+        a = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+        b = np.ascontiguousarray(np.transpose(B, (0, 2, 1))) if layout == 0 else np.ascontiguousarray(B)
+        c = np.ascontiguousarray(np.transpose(C0, (0, 2, 1)))
+        rc = fn(ctx.handle, a.ctypes.data, b.ctypes.data, c.ctypes.data, count, m, n, k, layout, lower, beta)
+        assert rc == 0, rc
+        got = np.transpose(c, (0, 2, 1))
+        ref = A @ B + (beta * C0 if beta != 0.0 else 0.0)
+        if lower:
+            ii, jj = np.indices((m, n))
+            ref = np.where(ii >= jj, ref, C0)      # entries above the diagonal keep their old value
+        tol = 4 * np.finfo(float).eps * k * 3
+        err = np.abs(got - ref).max()
+        assert err <= tol, (count, m, n, k, layout, lower, beta, err, tol)
+        if against_gemm2:
+            # bit for bit what k_gemm2 computes (same MFMA instruction, k-steps of a dot product in the same order)
+            for z in (0, count - 1):
+                c2 = np.asfortranarray(C0[z].copy())
+                a2 = np.asfortranarray(A[z])
+                b2 = np.asfortranarray(B[z]) if layout == 0 else np.ascontiguousarray(B[z])
+                rc = fn2(ctx.handle, a2.ctypes.data, b2.ctypes.data, c2.ctypes.data, m, n, k, 0 if layout == 0 else 1, 12, 1,
+                         1.0, beta, 0)
+                assert rc == 0
+                ref2 = c2 if not lower else np.where(np.indices((m, n))[0] >= np.indices((m, n))[1], c2, C0[z])
+                if layout == 0 or lower:            # (sc_dbg_gemm_host's NT mode is lower_only)
+                    assert np.array_equal(got[z], ref2), (m, n, k, layout, lower, np.abs(got[z] - ref2).max())
+        return got
+
+    return run
+
+
+@pytest.mark.parametrize("layout", [0, 2])
+@pytest.mark.parametrize("m,n,k", [(128, 64, 128), (256, 128, 256), (130, 66, 144), (2, 2, 128), (1000, 770, 160),
+                                   (48, 6, 512), (384, 1, 128) if False else (384, 2, 128), (1026, 1026, 256)])
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+def test_gemm3_shapes(gemm3, layout, m, n, k, beta):
+    """Full and ragged tiles in both dimensions, both operand layouts, C += A B and C = A B."""
+    gemm3(2, m, n, k, layout, beta=beta, seed=m + n + k)
+
+
+@pytest.mark.parametrize("m", [64, 126, 128, 130, 700, 1030, 2000])
+@pytest.mark.parametrize("k", [128, 256])
+def test_gemm3_lower_only(gemm3, m, k):
+    """The trailing update of the band reduction: lower triangle only, entries above the diagonal untouched."""
+    gemm3(3, m, m, k, 2, lower=1, seed=m)
+
+
+def test_gemm3_many_tiles_per_workgroup(gemm3):
+    """More tiles than workgroups (every CU walks several tiles: swap, prefetch of the next C, stores of the previous)."""
+    gemm3(5, 2048, 1280, 128, 0, seed=1)
+    gemm3(5, 2048, 1280, 128, 2, seed=2)
+    gemm3(9, 1408, 1408, 256, 2, lower=1, seed=3)
+    gemm3(4, 3000, 3000, 256, 0, beta=0.0, seed=4, against_gemm2=False)
+
+
+def test_gemm3_declines_what_it_does_not_take(gemm3):
+    """Odd m, K not a multiple of 16, K < 128: the launcher says no (callers then use k_gemm2)."""
+    from springcraft_amd import _hip
+
+    L = _hip.lib()
+    ctx = _hip.context()
+    z = np.zeros(1 << 16)
+    for m, n, k, layout in [(129, 64, 128, 0), (128, 64, 120, 0), (128, 64, 64, 0), (128, 65, 128, 2)]:
+        rc = L.sc_dbg_gemm3_host(ctx.handle, z.ctypes.data, z.ctypes.data, z.ctypes.data, 1, m, n, k, layout, 0, C.c_double(1.0))
+        assert rc != 0, (m, n, k, layout)
