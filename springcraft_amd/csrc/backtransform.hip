@@ -157,7 +157,14 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   if (nref <= 0) return SC_OK;
   const int nbt = BL.nbt;
   const int npanels = (nref + nbt - 1) / nbt;
-  const int w1s = std::min(BL.splits, w1_splits_for(ncols, batch));
+  int w1s = std::min(BL.splits, w1_splits_for(ncols, batch));
+  // W = V^T Z on k_gemm3 (the role-split kernel; its K loop runs at 0.84 of the MFMA peak against k_gemm2's 0.74) when the
+  // batch gives every CU a few of the 2 x ceil(ncols / 64) tiles per matrix without K slices; decided here because the
+  // records say where W goes (a single slice writes straight to where the update reads it)
+  static const bool env_w3 = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_W"); return !e || atoi(e) != 0; }();
+  const bool al16 = (n & 1) == 0 && (off & 1) == 0 && (stride_z & 1) == 0 && (stride_a & 1) == 0 && (nbt & 1) == 0;
+  const bool w_gemm3 = env_w3 && al16 && gemm3_would_take(ctx, batch, nbt, ncols, n - off, kGemmAkBk, false, 1.0, 0.0, al16);
+  if (w_gemm3) w1s = 1;
 
   // descriptor table: [gram | vt | w1 | update | x = G12 T2 | T12 = -T1 x] x npanels x batch  (each group contiguous
   // for one launch)
@@ -242,8 +249,14 @@ int backtransform_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, i
   for (int p = npanels - 1; p >= 0; --p) {
     const int mrow = n - p * nbt - off;
     t_w.start();
-    SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s, false, false,
-                           kGemmAkBk));
+    {
+      const int pc = std::min(nbt, n - p * nbt);
+      const bool al = al16 && ((p * nbt) & 1) == 0;
+      if (!w_gemm3 || launch_gemm3_uniform(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, pc, ncols, mrow, kGemmAkBk, false,
+                                           1.0, 0.0, al) != SC_OK)
+        SC_TRY(launch_gemm_f64(ctx, d_descs + 2 * grp + (size_t)p * batch, batch, nbt, ncols, kGemmTile, w1s, false, false,
+                               kGemmAkBk));
+    }
     if (w1s > 1) hipLaunchKernelGGL(k_bt_sum, dim3(256, (unsigned)batch), dim3(256), 0, st, d_bt_ws, BL, w1s, ncols);
     t_w.stop();
     t_u.start();

@@ -32,6 +32,7 @@
 //     B piece, B n-contiguous ("NT"):  k-pair (2 rows) as [x / 16][k & 1][16]     one instruction per k-pair
 //     B piece, B k-contiguous ("NN"):  8 columns x 16 k as [k / 2][x % 8][2]      one instruction per 8 columns; quarter q
 //                                       holds columns 16 q .. 16 q + 15 (all 16 k of the step)
+//     A k-contiguous ("TN"): pieces like those of a k-contiguous B: 8 rows x 16 k each, quarter q holds rows 32 q .. + 31
 //   C image: column c at c * kRow, 128 rows each.
 #include <algorithm>
 #include <cstdlib>
@@ -68,7 +69,7 @@ struct G3Args {
   int order;      // tile order: 0 flat (column by column, workgroup wg takes tiles wg, wg + 256, ...), 1 strips of four tile rows, 32 consecutive tiles per XCD
 };
 
-template <int LAYOUT>   // kGemmAmBn (2) or kGemmAmBk (0)
+template <int LAYOUT>   // kGemmAmBn (2), kGemmAmBk (0) or kGemmAkBk (1)
 __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -161,17 +162,26 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
     int l_ks = parity, l_slot = parity % kRing;
     while (lt.ok && l_ks >= KS) { l_ks -= KS; it_next(lt); }
     unsigned long long ab_t = 0, bb_t = 0, lda8 = 0, ldb8 = 0;
-    unsigned voff_a = 0, voff_b0 = 0, voff_b1 = 0;
+    unsigned voff_a[4] = {0, 0, 0, 0}, voff_b0 = 0, voff_b1 = 0;
     bool l_new = true;
     auto issue_group = [&]() {
       if (l_new) {
         const GemmDesc& D = P.descs[lt.z];
         const int row0 = lt.tm * 128, col0 = lt.tn * 64;
         const int mrem = min(128, P.m - row0), nrem = min(64, P.n - col0);
-        lda8 = uni64((unsigned long long)D.sa_k * 8ull);
-        ab_t = uni64((unsigned long long)(size_t)D.a + (unsigned long long)row0 * 8ull);
-        // rows / columns beyond the matrix: the lane re-reads the last valid pair (what lands there is never stored)
-        voff_a = (unsigned)min(lane * 16, (mrem - 2) * 8);
+        if (LAYOUT == kGemmAkBk) {
+          lda8 = uni64((unsigned long long)D.sa_i * 8ull);
+          ab_t = uni64((unsigned long long)(size_t)D.a + (unsigned long long)row0 * lda8);
+          // (rows beyond the matrix re-read the last row; what lands there is never stored)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            voff_a[i] = (unsigned)((unsigned long long)min(32 * q + 8 * i + (lane & 7), mrem - 1) * lda8 + (unsigned)(lane >> 3) * 16u);
+        } else {
+          lda8 = uni64((unsigned long long)D.sa_k * 8ull);
+          ab_t = uni64((unsigned long long)(size_t)D.a + (unsigned long long)row0 * 8ull);
+          // rows / columns beyond the matrix: the lane re-reads the last valid pair (what lands there is never stored)
+          voff_a[0] = voff_a[1] = voff_a[2] = voff_a[3] = (unsigned)min(lane * 16, (mrem - 2) * 8);
+        }
         if (LAYOUT == kGemmAmBn) {
           ldb8 = uni64((unsigned long long)D.sb_k * 8ull);
           bb_t = uni64((unsigned long long)(size_t)D.b + (unsigned long long)col0 * 8ull);
@@ -194,8 +204,13 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
       l_slot += 2;
       if (l_slot >= kRing) l_slot -= kRing;
       const unsigned m0v = lds_base + (unsigned)(slot_l * kSlot + q * kQuarter + 2880);
-      const unsigned long long ab = ab_t + (unsigned long long)(k0 + 4 * q) * lda8;
-      unsigned long long bb0, bb1;
+      unsigned long long a0, a1, a2, a3, bb0, bb1;
+      if (LAYOUT == kGemmAkBk) {
+        a0 = a1 = a2 = a3 = ab_t + (unsigned long long)k0 * 8ull;
+      } else {
+        a0 = ab_t + (unsigned long long)(k0 + 4 * q) * lda8;
+        a1 = a0 + lda8; a2 = a1 + lda8; a3 = a2 + lda8;
+      }
       if (LAYOUT == kGemmAmBn) {
         bb0 = bb_t + (unsigned long long)(k0 + 4 * q) * ldb8;
         bb1 = bb0 + 2ull * ldb8;
@@ -206,18 +221,19 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
       // scalar bases with the instruction offsets taken out (the offset moves the LDS and the global address alike).
       // s_nop 4: an SGPR written by a VALU instruction (v_readfirstlane / v_readlane of a spill) needs five wait states
       // before a global_* instruction reads it as its base, and hipcc pads nothing inside an asm statement.
-      const unsigned long long s0 = ab + 2880ull, s1 = ab + lda8 + 1728ull, s2 = ab + 2 * lda8 + 576ull,
-                               s3 = ab + 3 * lda8 - 576ull, s4 = bb0 - 1728ull, s5 = bb1 - 2880ull;
+      const unsigned long long s0 = a0 + 2880ull, s1 = a1 + 1728ull, s2 = a2 + 576ull, s3 = a3 - 576ull, s4 = bb0 - 1728ull,
+                               s5 = bb1 - 2880ull;
       asm volatile(
           "s_mov_b32 m0, %0\n\ts_nop 4\n\t"
-          "global_load_lds_dwordx4 %1, %4 offset:-2880\n\t"
-          "global_load_lds_dwordx4 %1, %5 offset:-1728\n\t"
-          "global_load_lds_dwordx4 %1, %6 offset:-576\n\t"
-          "global_load_lds_dwordx4 %1, %7 offset:576\n\t"
-          "global_load_lds_dwordx4 %2, %8 offset:1728\n\t"
-          "global_load_lds_dwordx4 %3, %9 offset:2880"
+          "global_load_lds_dwordx4 %1, %7 offset:-2880\n\t"
+          "global_load_lds_dwordx4 %2, %8 offset:-1728\n\t"
+          "global_load_lds_dwordx4 %3, %9 offset:-576\n\t"
+          "global_load_lds_dwordx4 %4, %10 offset:576\n\t"
+          "global_load_lds_dwordx4 %5, %11 offset:1728\n\t"
+          "global_load_lds_dwordx4 %6, %12 offset:2880"
           :
-          : "s"(m0v), "v"(voff_a), "v"(voff_b0), "v"(voff_b1), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5)
+          : "s"(m0v), "v"(voff_a[0]), "v"(voff_a[1]), "v"(voff_a[2]), "v"(voff_a[3]), "v"(voff_b0), "v"(voff_b1), "s"(s0),
+            "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5)
           : "memory");
     };
     if (lt.ok) issue_group();
@@ -362,11 +378,16 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
 
   // fragment addresses inside a slot (bytes): ONE per-lane offset per operand, everything else is an immediate of the
   // LDS instruction (a tile row step is 128 B, a k4 step a quarter)
-  const unsigned a_base = (unsigned)(fk * kRow + (wm * 64 + fr) * 8);
+  const unsigned a_base = LAYOUT == kGemmAkBk
+                              ? (unsigned)((2 * wm) * kQuarter + (fr >> 3) * kRow + (((fk >> 1) * 8 + (fr & 7)) * 16) + (fk & 1) * 8)
+                              : (unsigned)(fk * kRow + (wm * 64 + fr) * 8);
   const unsigned b_base = LAYOUT == kGemmAmBn
                               ? (unsigned)(4 * kRow + (fk >> 1) * kRow + (wn * 2) * 256 + (fk & 1) * 128 + fr * 8)
                               : (unsigned)((2 * wn) * kQuarter + 4 * kRow + (fr >> 3) * kRow + (((fk >> 1) * 8 + (fr & 7)) * 16) + (fk & 1) * 8);
   constexpr int kBni = LAYOUT == kGemmAmBn ? 256 : kQuarter, kBk4 = LAYOUT == kGemmAmBn ? kQuarter : 256;
+  // A: row tile mi and k-step k4 as immediates (k-contiguous A: 8-row pieces, two per row tile, four per quarter)
+  constexpr int kAk4 = LAYOUT == kGemmAkBk ? 256 : kQuarter;
+  auto a_mi = [](int mi) { return LAYOUT == kGemmAkBk ? (mi >> 1) * kQuarter + (mi & 1) * 2 * kRow : mi * 128; };
   char* cimg = lds + kRing * kSlot + (wn * 32 + fk) * kRow + (wm * 64 + fr) * 8;   // + (ni * 16 + 4 r) * kRow + mi * 128
   const bool with_c = P.beta_one != 0;
   // C(row = wm 64 + mi 16 + fr, col = wn 32 + ni 16 + fk + 4 r) <-> acc[ni][mi][r]
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
     const char* pa = sp + a_base;
     const char* pb = sp + b_base;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[buf][mi] = *(const double*)(pa + k4 * kQuarter + mi * 128);
+    for (int mi = 0; mi < 4; ++mi) af[buf][mi] = *(const double*)(pa + k4 * kAk4 + a_mi(mi));
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) bf[buf][ni] = *(const double*)(pb + k4 * kBk4 + ni * kBni);
   };
@@ -393,9 +414,15 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
   auto read_frags_asm = [&](int buf, unsigned slot_addr) {   // k4 = 0 of the slot at LDS byte address slot_addr
     const unsigned pa = slot_addr + a_base, pb = slot_addr + b_base;
     asm volatile("ds_read_b64 %0, %1" : "=v"(af[buf][0]) : "v"(pa) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(af[buf][1]) : "v"(pa) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(af[buf][2]) : "v"(pa) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:384" : "=v"(af[buf][3]) : "v"(pa) : "memory");
+    if (LAYOUT == kGemmAkBk) {
+      asm volatile("ds_read_b64 %0, %1 offset:2304" : "=v"(af[buf][1]) : "v"(pa) : "memory");
+      asm volatile("ds_read_b64 %0, %1 offset:6912" : "=v"(af[buf][2]) : "v"(pa) : "memory");
+      asm volatile("ds_read_b64 %0, %1 offset:9216" : "=v"(af[buf][3]) : "v"(pa) : "memory");
+    } else {
+      asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(af[buf][1]) : "v"(pa) : "memory");
+      asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(af[buf][2]) : "v"(pa) : "memory");
+      asm volatile("ds_read_b64 %0, %1 offset:384" : "=v"(af[buf][3]) : "v"(pa) : "memory");
+    }
     asm volatile("ds_read_b64 %0, %1" : "=v"(bf[buf][0]) : "v"(pb) : "memory");
     if (LAYOUT == kGemmAmBn) asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(bf[buf][1]) : "v"(pb) : "memory");
     else asm volatile("ds_read_b64 %0, %1 offset:6912" : "=v"(bf[buf][1]) : "v"(pb) : "memory");
@@ -490,31 +517,37 @@ int g_gemm3_order = -1;          // debugging (sc_dbg_gemm3_bench): tile order, 
 // caller uses launch_gemm_f64).  Taken: layout kGemmAmBn / kGemmAmBk, alpha = 1, beta in {0, 1}, k a multiple of 16 and
 // >= 128, m (and n for kGemmAmBn) even, pointers and leading dimensions that keep 16-byte alignment (aligned16: the
 // caller knows its records), enough tiles to give every CU a few.  lower: as launch_gemm_f64's lower_grid.
-int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
-                         double alpha, double beta, bool aligned16) {
+bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, bool lower, double alpha, double beta,
+                      bool aligned16) {
   static const int env = [] { const char* e = getenv("SPRINGCRAFT_GEMM3"); return e ? atoi(e) : 1; }();
-  if (env == 0 || count <= 0) return 1;
-  if (layout != kGemmAmBn && layout != kGemmAmBk) return 1;
-  if (alpha != 1.0 || (beta != 0.0 && beta != 1.0)) return 1;
-  if (!aligned16 || k < 128 || (k & 15) || (m & 1) || m < 2 || n < 1) return 1;
-  if (layout == kGemmAmBn && (n & 1)) return 1;
-  if (lower && m != n) return 1;
+  if (env == 0 || count <= 0) return false;
+  if (layout != kGemmAmBn && layout != kGemmAmBk && layout != kGemmAkBk) return false;
+  if (alpha != 1.0 || (beta != 0.0 && beta != 1.0)) return false;
+  if (!aligned16 || k < 128 || (k & 15) || (m & 1) || m < 2 || n < 1) return false;
+  if (layout == kGemmAmBn && (n & 1)) return false;
+  if (lower && m != n) return false;
   // (the lower-only trailing update of the band reduction: 0.66 against k_gemm2's 0.65 of the MFMA peak on 32 matrices
   // alone, 192 against 187 ms inside the C3 step -- its diagonal tiles store under lane predicates and its strips start
   // with few tiles --: left to k_gemm2 unless SPRINGCRAFT_GEMM3_LOWER = 1)
   static const bool env_lower = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_LOWER"); return e && atoi(e) != 0; }();
-  if (lower && !env_lower && !g_gemm3_any_size) return 1;
+  if (lower && !env_lower && !g_gemm3_any_size) return false;
   // (the kernel's tile order is built on 8 XCDs x 32 workgroups: a device -- or a partition -- with fewer CUs stays on k_gemm2)
-  const int cus = ctx->num_cus;
-  if (cus < 256) return 1;
+  if (ctx->num_cus < 256 || ctx->gemm3_attr == 0) return false;
   const long long TM = (m + 127) / 128, TN = (n + 63) / 64;
   const long long hN = TN / 2;
   const long long T1 = lower ? TM * TN - hN * (hN - 1) - ((TN & 1) ? hN : 0) : TM * TN;
   const long long total = T1 * count;
-  if (env != 2 && !g_gemm3_any_size && total < 4LL * 256) return 1;   // (SPRINGCRAFT_GEMM3 = 2: every launch that qualifies, for the tests)
-  if (total > 0x3fffffffLL) return 1;
+  if (env != 2 && !g_gemm3_any_size && total < 4LL * 256) return false;   // (SPRINGCRAFT_GEMM3 = 2: every launch that qualifies, for the tests)
+  return total <= 0x3fffffffLL;
+}
+
+int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
+                         double alpha, double beta, bool aligned16) {
+  if (!gemm3_would_take(ctx, count, m, n, k, layout, lower, alpha, beta, aligned16)) return 1;
   if (ctx->gemm3_attr < 0) {   // per device, hence per context
     const bool ok0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<kGemmAmBk>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kG3Lds) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<kGemmAkBk>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kG3Lds) == hipSuccess;
     const bool ok2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<kGemmAmBn>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kG3Lds) == hipSuccess;
@@ -525,6 +558,7 @@ int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, 
   G3Args A{d_desc, count, m, n, k, lower ? 1 : 0, beta != 0.0 ? 1 : 0, g_gemm3_order >= 0 ? g_gemm3_order : env_order};
   const unsigned grid = 256u;
   if (layout == kGemmAmBn) hipLaunchKernelGGL(k_gemm3<kGemmAmBn>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
+  else if (layout == kGemmAkBk) hipLaunchKernelGGL(k_gemm3<kGemmAkBk>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
   else hipLaunchKernelGGL(k_gemm3<kGemmAmBk>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
   if (hipGetLastError() != hipSuccess) {
     ctx->gemm3_attr = 0;   // refused once: this context stays on k_gemm2
@@ -560,7 +594,8 @@ extern "C" int sc_dbg_gemm3_host(sc_ctx* ctx, const double* a, const double* b, 
     D.a = da + ea * z; D.b = db + eb * z; D.c = dc + ec * z;
     D.m = m; D.n = n; D.k = k; D.ldc = m; D.alpha = 1.0; D.beta = beta;
     D.sa_i = 1; D.sa_k = m;
-    if (layout == kGemmAmBk) { D.sb_k = 1; D.sb_j = k; } else { D.sb_k = n; D.sb_j = 1; }
+    if (layout == kGemmAkBk) { D.sa_i = k; D.sa_k = 1; }   // a: count x (k x m) column-major
+    if (layout == kGemmAmBn) { D.sb_k = n; D.sb_j = 1; } else { D.sb_k = 1; D.sb_j = k; }
     D.lower_only = lower;
     h[(size_t)z] = D;
   }
@@ -589,7 +624,7 @@ extern "C" int sc_dbg_gemm3_bench(sc_ctx* ctx, int count, int m, int n, int k, i
   static const int ld_c = [] { const char* e = getenv("SC_DBG_LDC"); return e ? atoi(e) : 0; }();
   static const int ld_b = [] { const char* e = getenv("SC_DBG_LDB"); return e ? atoi(e) : 0; }();
   const int lda = std::max(m, ld_a), ldc = std::max(m, ld_c), ldbn = std::max(n, ld_b);
-  const size_t ea = (size_t)lda * k, eb = layout == kGemmAmBk ? (size_t)k * n : (size_t)ldbn * k, ec = (size_t)ldc * n;
+  const size_t ea = (size_t)lda * k, eb = layout == kGemmAmBn ? (size_t)ldbn * k : (size_t)k * n, ec = (size_t)ldc * n;
   char* base = nullptr;
   SC_HIP(ctx, hipMalloc((void**)&base, (ea + eb + ec) * count * 8 + sizeof(GemmDesc) * (size_t)count + 256));
   double* da = (double*)base;
@@ -612,7 +647,8 @@ extern "C" int sc_dbg_gemm3_bench(sc_ctx* ctx, int count, int m, int n, int k, i
     D.a = da + ea * z; D.b = db + eb * z; D.c = dc + ec * z;
     D.m = m; D.n = n; D.k = k; D.ldc = ldc; D.alpha = 1.0; D.beta = 1.0;
     D.sa_i = 1; D.sa_k = lda;
-    if (layout == kGemmAmBk) { D.sb_k = 1; D.sb_j = k; } else { D.sb_k = ldbn; D.sb_j = 1; }
+    if (layout == kGemmAkBk) { D.sa_i = k; D.sa_k = 1; }
+    if (layout == kGemmAmBn) { D.sb_k = ldbn; D.sb_j = 1; } else { D.sb_k = 1; D.sb_j = k; }
     D.lower_only = lower;
     h[(size_t)z] = D;
   }

@@ -58,3 +58,6 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
 // launch that qualifies whatever its size (tests).
 int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
                          double alpha, double beta, bool aligned16);
+// (the launcher's decision without the launch: callers that lay out their records differently for the two kernels)
+bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, bool lower, double alpha, double beta,
+                      bool aligned16);

@@ -109,8 +109,9 @@ def gemm3():
         B = rs.uniform(-1, 1, (count, k, n))
         C0 = rs.uniform(-1, 1, (count, m, n))
         # per matrix column-major: A (i, kk) at kk*m + i; B (kk, j) at j*k + kk (layout 0) or kk*n + j (layout 2)
-        a = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
-        b = np.ascontiguousarray(np.transpose(B, (0, 2, 1))) if layout == 0 else np.ascontiguousarray(B)
+        # (layout 1: A stored k-contiguous, per matrix (k x m) column-major = A itself in C order)
+        a = np.ascontiguousarray(np.transpose(A, (0, 2, 1))) if layout != 1 else np.ascontiguousarray(A)
+        b = np.ascontiguousarray(np.transpose(B, (0, 2, 1))) if layout != 2 else np.ascontiguousarray(B)
         c = np.ascontiguousarray(np.transpose(C0, (0, 2, 1)))
         rc = fn(ctx.handle, a.ctypes.data, b.ctypes.data, c.ctypes.data, count, m, n, k, layout, lower, beta)
         assert rc == 0, rc
@@ -126,20 +127,20 @@ def gemm3():
             # bit for bit what k_gemm2 computes (same MFMA instruction, k-steps of a dot product in the same order)
             for z in (0, count - 1):
                 c2 = np.asfortranarray(C0[z].copy())
-                a2 = np.asfortranarray(A[z])
-                b2 = np.asfortranarray(B[z]) if layout == 0 else np.ascontiguousarray(B[z])
-                rc = fn2(ctx.handle, a2.ctypes.data, b2.ctypes.data, c2.ctypes.data, m, n, k, 0 if layout == 0 else 1, 12, 1,
+                a2 = np.asfortranarray(A[z]) if layout != 1 else np.ascontiguousarray(A[z])
+                b2 = np.asfortranarray(B[z]) if layout != 2 else np.ascontiguousarray(B[z])
+                rc = fn2(ctx.handle, a2.ctypes.data, b2.ctypes.data, c2.ctypes.data, m, n, k, {0: 0, 1: 2, 2: 1}[layout], 12, 1,
                          1.0, beta, 0)
                 assert rc == 0
                 ref2 = c2 if not lower else np.where(np.indices((m, n))[0] >= np.indices((m, n))[1], c2, C0[z])
-                if layout == 0 or lower:            # (sc_dbg_gemm_host's NT mode is lower_only)
+                if layout != 2 or lower:            # (sc_dbg_gemm_host's NT mode is lower_only)
                     assert np.array_equal(got[z], ref2), (m, n, k, layout, lower, np.abs(got[z] - ref2).max())
         return got
 
     return run
 
 
-@pytest.mark.parametrize("layout", [0, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("m,n,k", [(128, 64, 128), (256, 128, 256), (130, 66, 144), (2, 2, 128), (1000, 770, 160),
                                    (48, 6, 512), (384, 1, 128) if False else (384, 2, 128), (1026, 1026, 256)])
 @pytest.mark.parametrize("beta", [1.0, 0.0])
@@ -159,6 +160,7 @@ def test_gemm3_many_tiles_per_workgroup(gemm3):
     """More tiles than workgroups (every CU walks several tiles: swap, prefetch of the next C, stores of the previous)."""
     gemm3(5, 2048, 1280, 128, 0, seed=1)
     gemm3(5, 2048, 1280, 128, 2, seed=2)
+    gemm3(6, 256, 3000, 1744, 1, beta=0.0, seed=5)      # W = V^T Z of the back-transformation: two row tiles, long K
     gemm3(9, 1408, 1408, 256, 2, lower=1, seed=3)
     gemm3(4, 3000, 3000, 256, 0, beta=0.0, seed=4, against_gemm2=False)
 
