@@ -2365,26 +2365,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   auto store_rows_b = [&](const Raw& v, int row0) { store_half(eb, col_b < ncols, v.b, row0); };
   // scatter_tile in two pieces: raw tile -> transposition tile -> four values per lane (scatter_in); masks and the move
   // into the accumulator layout a few MFMAs later, when the LDS reads have come back (scatter_out)
+  // (round 5: a tile inside the matrix, all columns of the workgroup inside too, takes ONE scalar branch and no vector
+  // compare / select / index arithmetic at all -- every VALU instruction between two MFMAs costs matrix-pipe time: eight
+  // v_xor per 32 MFMAs cost k_gemm3's K loop 6 %)
   auto scatter_in = [&](const Raw& raw, double (&tmp)[4], int row0) {
     *(d2u*)(stg + gc * 18 + gr) = raw.a;
     *(d2u*)(stg + (gc + 8) * 18 + gr) = raw.b;
     asm volatile("" ::: "memory");
-    const int shift = row0 < n - 16 ? 0 : row0 - (n - 16);
+    if (row0 < n - 16) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * r + fk + shift;
-      tmp[r] = stg[fr * 18 + (i < 16 ? i : 15)];
+      for (int r = 0; r < 4; ++r) tmp[r] = stg[fr * 18 + 4 * r + fk];
+    } else {
+      const int shift = row0 - (n - 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + fk + shift;
+        tmp[r] = stg[fr * 18 + (i < 16 ? i : 15)];
+      }
     }
     asm volatile("" ::: "memory");
   };
   auto scatter_out = [&](d4& t, const double (&tmp)[4], int row0) {
     double x[4];
+    if (full_cols && row0 + 16 <= n) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      x[r] = (col_ok && row0 + 4 * r + fk < n) ? tmp[r] : 0.0;
-      // (pinned here: the values are only used by the next diamond, and the compiler would otherwise sink the selects
-      // to the end of this one, where nothing overlaps them)
-      asm volatile("" : "+v"(x[r]));
+      for (int r = 0; r < 4; ++r) {
+        x[r] = tmp[r];
+        asm volatile("" : "+v"(x[r]));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[r] = (col_ok && row0 + 4 * r + fk < n) ? tmp[r] : 0.0;
+        // (pinned here: the values are only used by the next diamond, and the compiler would otherwise sink the selects
+        // to the end of this one, where nothing overlaps them)
+        asm volatile("" : "+v"(x[r]));
+      }
     }
     t = d4{x[0], x[1], x[2], x[3]};
   };
@@ -2432,7 +2448,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
     const unsigned ga_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga);
     const unsigned ga_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32));
     const unsigned lq = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(slot * kHalfDoubles) * 8u + (unsigned)qc * 1024u);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lq) : "memory");
+    // (s_nop 4: the scalar base below comes out of v_readfirstlane, and an SGPR written by a VALU instruction needs five
+    // wait states before a global_* instruction reads it as its base -- hipcc pads nothing around an asm statement;
+    // found in round 5 on k_gemm3, where a base reloaded from a spill lane right in front of the DMA read as zero)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4" : : "s"(lq) : "memory");
     return ((unsigned long long)ga_hi << 32) | (unsigned long long)ga_lo;
   };
   auto dma_go = [&](unsigned long long sbase, int i) {   // i = 0 .. 4 (a constant after unrolling)
