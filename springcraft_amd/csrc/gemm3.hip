@@ -529,8 +529,10 @@ bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, b
   // (the lower-only trailing update of the band reduction: 0.66 against k_gemm2's 0.65 of the MFMA peak on 32 matrices
   // alone, 192 against 187 ms inside the C3 step -- its diagonal tiles store under lane predicates and its strips start
   // with few tiles --: left to k_gemm2 unless SPRINGCRAFT_GEMM3_LOWER = 1)
-  static const bool env_lower = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_LOWER"); return e && atoi(e) != 0; }();
-  if (lower && !env_lower && !g_gemm3_any_size) return false;
+  // For a few large matrices it wins (one n = 24000 matrix, config C5: 186 -> 178 ms of trailing updates per solve): there
+  // the two half batches on two streams, whose panel QRs hide beside k_gemm2's workgroups, do not exist.
+  static const int env_lower = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_LOWER"); return e ? atoi(e) : -1; }();
+  if (lower && !g_gemm3_any_size && (env_lower == 0 || (env_lower < 0 && count >= 8))) return false;
   // (the kernel's tile order is built on 8 XCDs x 32 workgroups: a device -- or a partition -- with fewer CUs stays on k_gemm2)
   if (ctx->num_cus < 256 || ctx->gemm3_attr == 0) return false;
   const long long TM = (m + 127) / 128, TN = (n + 63) / 64;

@@ -20,12 +20,15 @@ solver.solve(coord); torch.cuda.synchronize()
 t = solver.last_timings()
 print(f"{t['bulge_chasing_ms']:.1f}")
 '''
-MODES = (("pair", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "2"}),
+MODES = (("pair", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "2", "SPRINGCRAFT_BULGE_PAIR_MAX": "1000000"}),
          ("sweep/wg", {"SPRINGCRAFT_BULGE_PERSISTENT": "2", "SPRINGCRAFT_BULGE_PAIR": "0"}),
          ("per-wavefront", {"SPRINGCRAFT_BULGE_PERSISTENT": "0"}))
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+ext = len(sys.argv) > 1 and sys.argv[1] == "ext"   # beyond the round-4 range: more matrices per XCD than pair workgroups fit
 points = [(500, 64), (1000, 16), (1000, 32), (1000, 64), (2000, 8), (2000, 16), (2000, 32), (2000, 64)] if quick else [
     (n_atoms, B) for n_atoms in (342, 500, 1000, 2000) for B in (4, 8, 16, 32, 64)]
+if ext:
+    points = [(2000, 64), (2000, 96), (1000, 128), (1000, 256), (500, 256), (342, 512)]
 for n_atoms, B in points:
     if n_atoms * n_atoms * 9 * B * 8 * 4 > 200e9:
         continue

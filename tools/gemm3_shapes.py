@@ -25,6 +25,9 @@ shapes = [
     ("square (NN)", 6144, 6144, 256, 0, 0),
     ("square (NT)", 6144, 6144, 256, 2, 0),
 ]
+if len(sys.argv) > 2 and sys.argv[2] == "dc":
+    shapes = [("merge, top level (NN)", 3000, 3488, 3488, 0, 0), ("merge, level below (NN)", 1500, 1744, 1744, 0, 0),
+              ("merge, third level (NN)", 750, 880, 880, 0, 0)]
 if len(sys.argv) > 2 and sys.argv[2] == "ld":
     shapes = [("NN", 6000, 6000, 256, 0, 0), ("NT lower", 5936, 5936, 256, 2, 1)]
 if len(sys.argv) > 2 and sys.argv[2] == "edges":

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round-5 evidence on one GPU box, in parts (a gpurun call is limited to 20 minutes):
+#   bash tools/r05_final.sh a   the -m gpu suite with durations, the four bench lines (C3 with the CPU baseline), latencies
+#   bash tools/r05_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
+#                               runs) of k_bt2_apply -- bytes and MFMA-pipe occupancy at the benchmarked batch -- and the
+#                               MFMA-pipe occupancy of k_gemm3
+#   bash tools/r05_final.sh c1 | c2   the test matrix (tools/test_matrix.sh), in two halves
+#   bash tools/r05_final.sh d   k_gemm3 beside k_gemm2 on the batched shapes of the step, the chase sweep with the points
+#                               beyond the round-4 range, per-phase stamps of k_bulge_chase at C4's shape
+# Everything lands in gpurun_out/r05_final/; what is to be judged is copied to profiles/r05_* (profiles/README.md).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r05_final
+mkdir -p $OUT
+cd $ROOT
+part=${1:-a}
+if [ $part = a ]; then
+  timeout -k 10 900 python -m pytest tests -m gpu -q --durations=15 > $OUT/gputest_durations.txt 2>&1 || { tail -30 $OUT/gputest_durations.txt; exit 1; }
+  tail -3 $OUT/gputest_durations.txt
+  timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+  python tools/show_bench.py $OUT/bench.json
+  for c in c2 c4 c5; do
+    timeout -k 10 300 python bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err || { tail -5 $OUT/bench_$c.err; exit 1; }
+    python tools/show_bench.py $OUT/bench_$c.json
+  done
+  timeout -k 10 200 python tools/latency_phases.py > $OUT/latency.txt 2>&1 || exit 1
+  grep -v amdgpu.ids $OUT/latency.txt
+elif [ $part = b ]; then
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench --output-format csv -- \
+     python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err) || { tail -5 $OUT/bench_under_rocprof.err; exit 1; }
+  rm -f $OUT/prof/*kernel_trace.csv $OUT/prof/*/*kernel_trace.csv
+  cp $(ls $OUT/prof/*kernel_stats.csv $OUT/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_bench.csv
+  head -8 $OUT/rocprofv3_kernel_stats_bench.csv
+  bash tools/pmc_kernel.sh k_bt2_apply r05_bt2 || exit 1
+  bash tools/pmc_mfma.sh k_bt2_apply r05_bt2 || exit 1
+  bash tools/pmc_mfma.sh k_gemm3 r05_gemm3 || exit 1
+  cp -r gpurun_out/pmc_r05_bt2 gpurun_out/pmc_r05_gemm3 $OUT/ 2>/dev/null
+elif [ $part = c1 ]; then
+  bash tools/test_matrix.sh 1 > $OUT/test_matrix_1.txt 2>&1
+  cat $OUT/test_matrix_1.txt
+elif [ $part = c2 ]; then
+  bash tools/test_matrix.sh 2 > $OUT/test_matrix_2.txt 2>&1
+  cat $OUT/test_matrix_2.txt
+else
+  timeout -k 10 300 python tools/gemm3_shapes.py 32 2>&1 | grep -v amdgpu.ids | cut -c1-260 > $OUT/gemm3_shapes.txt
+  cat $OUT/gemm3_shapes.txt
+  timeout -k 10 500 python tools/bulge_sweep.py ext > $OUT/bulge_sweep_ext.txt 2>&1
+  cat $OUT/bulge_sweep_ext.txt
+fi
+echo "part $part done"

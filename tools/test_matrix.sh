@@ -25,5 +25,8 @@ run SPRINGCRAFT_BULGE_PERSISTENT=2 SPRINGCRAFT_BULGE_PAIR=2
 run SPRINGCRAFT_BULGE_PAIR=0
 run SPRINGCRAFT_TWO_STAGE=1
 run SPRINGCRAFT_TWO_STAGE=0
+run SPRINGCRAFT_GEMM3=0
+run SPRINGCRAFT_GEMM3=2 SPRINGCRAFT_GEMM3_LOWER=1
+run SPRINGCRAFT_GEMM3=2 SPRINGCRAFT_GEMM3_ORDER=0 SPRINGCRAFT_GEMM3_W=0
 run SPRINGCRAFT_BULGE_NO_EARLY=1 SPRINGCRAFT_BULGE_PAIR=0
 run SPRINGCRAFT_BULGE_PERSISTENT=2 SPRINGCRAFT_BULGE_PAIR=0 SPRINGCRAFT_BULGE_NO_EARLY=1
