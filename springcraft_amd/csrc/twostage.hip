@@ -2712,6 +2712,330 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   BT2_STAMP_WRITE
 }
 
+// ================================================================================================================
+// k_bt2_role (round 5): the same product Z <- Q2 Z with the ROLES of a workgroup's waves split, as in k_gemm3
+// (gemm3.hip).  k_bt2_apply's eight waves each do everything -- MFMAs, the LDS-DMA of the fragments, the loads /
+// transposition / masks / stores of the window rows -- and every one of their memory and vector instructions costs the
+// SIMD's matrix pipe time (the pipes are busy 0.79 of that launch).  Here
+//   * waves 0-3 are one MFMA wave per SIMD, 16 columns each (a workgroup = 64 columns of one matrix): the 128-row window
+//     in three arrays of four accumulator tiles that rotate through three code phases exactly as in k_bt2_apply, 160
+//     MFMAs per diamond from ready-made fragments in LDS -- and nothing else but LDS reads / writes: the 64 rows that enter
+//     the window at a slide are read from an LDS image in accumulator layout, the 64 finished rows are written to one;
+//   * waves 4-7 stream the fragments a quarter-diamond (one mini: 20 KB, five 1-KB pieces per wave behind ONE write of
+//     M0) at a time into a ring of three quarter buffers, two quarters ahead;
+//   * waves 8-11 (one per MFMA wave) move the window rows: LDS-DMA of the entering rows, column by column (512 bytes per
+//     instruction: lanes 0-31), into one of two images, a whole diamond before the MFMA wave reads them, and
+//     16-byte-per-lane stores of the finished rows out of a third image; they also zero what lies below the matrix, so
+//     the MFMA waves need no masks.
+// One barrier per quarter-diamond; per sweep group two more in front (the window's two halves come in through the two
+// images) and four behind (they go out).  LDS: 3 x 20 KB + 3 x 4 x 8 448 B = 162 816 B.
+// (Version 1 -- ring of two half-diamond buffers, one image in, everything fetched one half ahead -- was correct and took
+// 999 ms per C3 step against k_bt2_apply's 605: a loader's two M0 groups per half land one after the other, and the
+// entering rows come from HBM: both sat on the critical path of every diamond.)
+// Image layout: column c of a wave's 16 at c * 528 B (64 rows + 16 B: an accumulator register's 16 columns x 2 rows fall
+// into 32 distinct 8-byte bank pairs).  Needs n even (the window starts at an odd row and moves in pairs of rows) --
+// bt2_batched checks.
+constexpr int kRoleCol = 528;                       // bytes between the columns of a window image
+constexpr int kRoleImg = 16 * kRoleCol;             // one wave's image: 16 columns x 64 rows
+constexpr int kQuarterBytes = kMiniFrags * 64 * 8;  // 20 480
+constexpr int kRoleRing = 3 * kQuarterBytes;
+constexpr int kRoleLds = kRoleRing + 3 * 4 * kRoleImg;
+
+__device__ __forceinline__ unsigned long long role_uni64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ sb_all, SbLayout SL,
+                                                     const int* __restrict__ dia_off, double* __restrict__ z_all,
+                                                     long long stride_z, int ncols, int batch) {
+  extern __shared__ __attribute__((aligned(16))) char rl[];   // ring of 3 quarter buffers | 2 x 4 images in | 4 images out
+  const int n = SL.n;
+  const int nchunk = (ncols + 63) / 64;
+  const int xcd = blockIdx.x & 7, slot_wg = blockIdx.x >> 3;
+  const int mat = xcd + 8 * (slot_wg / nchunk), chunk = slot_wg % nchunk;   // all column chunks of a matrix on one XCD
+  if (mat >= batch) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)rl;
+  const int ngroups = SL.ngroups;
+  auto barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // diamonds of sweep group S (read from global memory: made uniform for the compiler)
+  auto group_d0 = [&](int S) { return __builtin_amdgcn_readfirstlane(dia_off[S]); };
+
+  if (w >= 4 && w < 8) {
+    // ------------------------------------------------------------------------------------------ fragment loaders
+    // wave lw fetches pieces 5 lw .. 5 lw + 4 of a quarter (20 pieces of 1 KB) behind ONE write of M0.  A write to M0
+    // waits for the wave's LDS-DMA in flight: issuing quarter q + 2 therefore also means that quarter q + 1 has landed.
+    const int lw = w - 4;
+    const unsigned voff = (unsigned)lane * 16u;
+    const double* sb = sb_all + (size_t)mat * SL.slab;
+    auto fetch_quarter = [&](const double* src, int buf) {
+      // (scalar by construction: kernel arguments, blockIdx, readfirstlane'd counters -- no VALU instruction in this wave's
+      // loop: a helper wave's VALU instructions wait for issue slots of a SIMD that the MFMA wave keeps busy)
+      const unsigned long long g = (unsigned long long)(size_t)src + (unsigned long long)(5 * lw + 2) * 1024ull;
+      const unsigned m0v = lds_base + (unsigned)(buf * kQuarterBytes + (5 * lw + 2) * 1024);
+      asm volatile(
+          "s_mov_b32 m0, %0\n\ts_nop 4\n\t"
+          "global_load_lds_dwordx4 %1, %2 offset:-2048\n\t"
+          "global_load_lds_dwordx4 %1, %2 offset:-1024\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\t"
+          "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+          "global_load_lds_dwordx4 %1, %2 offset:2048"
+          :
+          : "s"(m0v), "v"(voff), "s"(g)
+          : "memory");
+    };
+    for (int S = ngroups - 1; S >= 0; --S) {
+      const int d0 = group_d0(S), nk = group_d0(S + 1) - d0;
+      const int nq = 4 * nk;
+      const char* fgrp = (const char*)(sb + SL.frag + (size_t)d0 * kFragDoubles);
+      fetch_quarter((const double*)fgrp, 0);
+      fetch_quarter((const double*)(fgrp + kQuarterBytes), 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      barrier();   // b0
+      barrier();   // b1
+      int buf = 2;
+      for (int q = 0; q < nq; ++q) {
+        barrier();   // quarter q starts; the buffer of quarter q - 1 is free
+        if (q + 2 < nq) {
+          fetch_quarter((const double*)(fgrp + (size_t)(q + 2) * kQuarterBytes), buf);
+          // quarter q + 1 (the five instructions before these five) must have LANDED at the next barrier: an explicit
+          // count -- the wait that a write to M0 implies is not one to build on (version 2 without it: wrong results in
+          // some members of a batch)
+          asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      barrier(); barrier(); barrier(); barrier();   // e0 .. e3
+    }
+    return;
+  }
+
+  if (w >= 8) {
+    // ------------------------------------------------------------------------------------------------- Z waves
+    const int zw = w - 8;
+    const int c0 = chunk * 64 + 16 * zw;                       // first of this wave's 16 columns
+    double* z_mat = z_all + (size_t)mat * stride_z;
+    const unsigned img_in0 = lds_base + (unsigned)(kRoleRing + zw * kRoleImg);
+    char* p_in0 = rl + kRoleRing + zw * kRoleImg;
+    char* p_out = rl + kRoleRing + 8 * kRoleImg + zw * kRoleImg;
+    const unsigned long long col8 = (unsigned long long)n * 8ull;
+    // rows row0 .. row0 + 63 of the 16 columns -> image `which` (lanes 0-31: rows row0 + 2 l, + 1 of one column per
+    // instruction; M0 = the middle of the image; rows beyond the matrix re-read its last pair and are put right by fix_rows)
+#define ROLE_DMA(J, IMM)                                                                                                     \
+  {                                                                                                                          \
+    const unsigned long long b_ = (unsigned long long)(size_t)z_mat +                                                       \
+                                  (unsigned long long)min(c0 + (J), ncols - 1) * col8 - (unsigned long long)(long long)(IMM);  \
+    asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #IMM : : "v"(voff), "s"(b_) : "memory");               \
+  }
+    auto fetch_rows = [&](int row0, int which) {
+      const int rr = min(row0 + 2 * (lane & 31), n - 2);
+      const unsigned voff = (unsigned)rr * 8u;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(img_in0 + (unsigned)(which * 4 * kRoleImg) + 3960u) : "memory");
+      if (lane < 32) {
+        ROLE_DMA(0, -3960) ROLE_DMA(1, -3432) ROLE_DMA(2, -2904) ROLE_DMA(3, -2376)
+        ROLE_DMA(4, -1848) ROLE_DMA(5, -1320) ROLE_DMA(6, -792) ROLE_DMA(7, -264)
+        ROLE_DMA(8, 264) ROLE_DMA(9, 792) ROLE_DMA(10, 1320) ROLE_DMA(11, 1848)
+        ROLE_DMA(12, 2376) ROLE_DMA(13, 2904) ROLE_DMA(14, 3432) ROLE_DMA(15, 3960)
+      }
+    };
+#undef ROLE_DMA
+    // (after the rows have landed) what lies below the matrix reads as zero; a pair that straddles the last row was read
+    // one row early: its second value is the last row
+    auto fix_rows = [&](int row0, int which) {
+      if (row0 + 64 <= n) return;
+      typedef double d2z __attribute__((ext_vector_type(2)));
+      if (lane < 32) {
+        const int r = row0 + 2 * lane;
+        for (int j = 0; j < 16; ++j) {
+          d2z* u = (d2z*)(p_in0 + which * 4 * kRoleImg + j * kRoleCol + lane * 16);
+          if (r >= n) *u = d2z{0.0, 0.0};
+          else if (r == n - 1) { const d2z v = *u; *u = d2z{v[1], 0.0}; }
+        }
+      }
+    };
+    // image out -> rows row0 .. row0 + 63 of the 16 columns, two columns per instruction: scalar base of the column pair +
+    // one lane offset, the predicates (rows / columns that exist) once per call
+    auto store_rows = [&](int row0) {
+      typedef double d2z __attribute__((ext_vector_type(2)));
+      const int jj = lane >> 5, pos = lane & 31;
+      const int r = row0 + 2 * pos;
+      unsigned img_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p_out + (unsigned)(jj * kRoleCol + pos * 16);
+      asm volatile("" : "+v"(img_a));
+      const __attribute__((address_space(3))) char* img = (const __attribute__((address_space(3))) char*)(size_t)img_a;
+      const unsigned voff = (unsigned)((unsigned long long)jj * col8) + (unsigned)r * 8u;
+      const bool full = r + 1 < n, half = r + 1 == n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const d2z v = *(const __attribute__((address_space(3))) d2z*)(img + 2 * i * kRoleCol);
+        const unsigned long long b = (unsigned long long)(size_t)z_mat + (unsigned long long)(c0 + 2 * i) * col8;
+        const bool col_ok = c0 + 2 * i + jj < ncols;
+        if (full && col_ok) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(b) : "memory");
+        if (half && col_ok) {
+          const double lo = v[0];
+          asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(lo), "s"(b) : "memory");
+        }
+      }
+    };
+    for (int S = ngroups - 1; S >= 0; --S) {
+      const int d0 = group_d0(S), nk = group_d0(S + 1) - d0;
+      const int win0 = S * kG + 1;
+      fetch_rows(win0, 0);
+      fetch_rows(win0 + 64, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fix_rows(win0, 0);
+      fix_rows(win0 + 64, 1);
+      barrier();   // b0: both halves of the window are in the images
+      barrier();   // b1: the MFMA wave has read them
+      // E_k = the rows that enter after diamond k (rows win_k + 128 ..), read by the MFMA wave at the end of diamond k out of
+      // image k & 1; fetched a whole diamond earlier
+      if (1 < nk) fetch_rows(win0 + 128, 0);
+      for (int k = 0; k < nk; ++k) {
+        const int win = win0 + 64 * k;
+        barrier();   // quarter 0 (the rows finished at the last slide went into the image out at the end of the last diamond)
+        barrier();   // quarter 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // E_k (fetched a diamond ago) has landed; the last diamond's stores are out
+        if (k + 1 < nk) fix_rows(win + 128, k & 1);
+        if (k > 0) store_rows(win - 64);
+        barrier();   // quarter 2
+        barrier();   // quarter 3: at its end the MFMA wave reads E_k
+        if (k + 2 < nk) fetch_rows(win + 192, (k + 1) & 1);   // E_{k+1} into the image that was read a diamond ago
+      }
+      const int winl = win0 + 64 * (nk - 1);
+      barrier();   // e0
+      barrier();   // e1: rows winl .. + 63 are in the image out
+      store_rows(winl);
+      barrier();   // e2 (they have been read)
+      barrier();   // e3: rows winl + 64 .. + 127
+      store_rows(winl + 64);
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- MFMA waves
+  const int fr = lane & 15, fk = lane >> 4;
+  // this lane's place in a window image: column fr, row fk (+ 16 per tile, + 4 per register)
+  char* q_in0 = rl + kRoleRing + w * kRoleImg + fr * kRoleCol + fk * 8;
+  char* q_out = q_in0 + 8 * kRoleImg;
+  // The window: eight accumulator tiles (128 rows x 16 columns), ONE copy of the code.  (k_bt2_apply keeps three arrays of
+  // four tiles and three code phases so that the slide is a renaming; with the 168 registers of a 12-wave workgroup hipcc
+  // moved accumulator tuples through scratch where the phases join -- 44 spills per three diamonds, each reload a wait
+  // for memory in the MFMA stream: 1 130 ms.  Here the slide is 16 register moves per diamond: the finished rows go to
+  // the image out right behind the diamond's last MFMA, the lower half moves up, the entering rows land in its place.)
+  d4 zz[8];
+  typedef double d2l __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) char* lcp;
+  // One quarter-diamond = one mini (st = 3 - QI): 20 MFMAs of W = V^T Z, 20 of Z -= (V T) W, fragments at `ring`.
+  auto quarter = [&](auto QI, const char* ring) {
+    constexpr int st = 3 - decltype(QI)::value;
+    // (addresses re-materialised at the point of use: hoisted out of the loops every "base + constant" becomes a register of
+    // its own; opaque here, the constants go into the LDS instructions' offset fields)
+    unsigned ring_a = (unsigned)(size_t)(lcp)ring + (unsigned)lane * 16u;
+    asm volatile("" : "+v"(ring_a));
+    const __attribute__((address_space(3))) d2l* ldsP = (const __attribute__((address_space(3))) d2l*)(size_t)ring_a;
+    d4 wa = d4{0, 0, 0, 0};
+    constexpr int kAhead = 8;
+    double fq[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead / 2; ++j) {
+      const d2l t = ldsP[j * 64];
+      fq[2 * j] = t[0];
+      fq[2 * j + 1] = t[1];
+    }
+#pragma unroll
+    for (int p = 0; p < kMiniFrags; ++p) {
+      const double a = fq[p % kAhead];
+      if (p < 20) {
+        const int rt = st + p / 4, r = p % 4;
+        wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zz[rt][r], p == 0 ? d4{0, 0, 0, 0} : wa, 0, 0, 0);
+      } else {
+        const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
+        zz[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], zz[rt], 0, 0, 0);
+      }
+      if ((p & 1) && p + kAhead - 1 < kMiniFrags) {
+        const d2l t = ldsP[((p + kAhead - 1) / 2) * 64];
+        fq[(p - 1) % kAhead] = t[0];
+        fq[p % kAhead] = t[1];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the order as written: fragment reads a few MFMAs ahead, not all at once)
+    }
+  };
+  // four tiles <-> an image (64 rows x 16 columns), a tile at a time
+  auto tiles_in = [&](int base, const char* img_) {
+    unsigned img_a = (unsigned)(size_t)(lcp)img_;
+    asm volatile("" : "+v"(img_a));
+    lcp img = (lcp)(size_t)img_a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zz[base + i][r] = *(const __attribute__((address_space(3))) double*)(img + (16 * i + 4 * r) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto tiles_out = [&](int base) {
+    unsigned out_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)q_out;
+    asm volatile("" : "+v"(out_a));
+    __attribute__((address_space(3))) char* qo = (__attribute__((address_space(3))) char*)(size_t)out_a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(__attribute__((address_space(3))) double*)(qo + (16 * i + 4 * r) * 8) = zz[base + i][r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  for (int S = ngroups - 1; S >= 0; --S) {
+    const int nk = group_d0(S + 1) - group_d0(S);
+    barrier();                 // b0: the window's two halves are in the two images
+    tiles_in(0, q_in0);
+    tiles_in(4, q_in0 + 4 * kRoleImg);
+    barrier();                 // b1
+    int buf = 0;               // 4 k % 3: the ring buffer of the diamond's first quarter
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < nk; ++k) {
+      const char* r0 = rl + buf * kQuarterBytes;
+      const char* r1 = rl + (buf + 1 > 2 ? buf - 2 : buf + 1) * kQuarterBytes;
+      const char* r2 = rl + (buf + 2 > 2 ? buf - 1 : buf + 2) * kQuarterBytes;
+      barrier();
+      quarter(I0{}, r0);
+      barrier();
+      quarter(I1{}, r1);
+      barrier();
+      quarter(I2{}, r2);
+      barrier();
+      quarter(I3{}, r0);                         // (4 k + 3) % 3 = 4 k % 3
+      if (k + 1 < nk) {
+        // the slide: the finished rows into the image out (the Z wave stores them during the next diamond), the lower half
+        // of the window up, E_k -- the rows that enter -- into its place
+        tiles_out(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zz[i] = zz[4 + i];
+        tiles_in(4, q_in0 + (k & 1) * 4 * kRoleImg);
+      }
+      buf = buf == 2 ? 0 : buf + 1;   // 4 (k + 1) % 3 = (4 k + 1) % 3
+    }
+    // the window of the last diamond goes back to memory
+    barrier();                                   // e0: the image out is free
+    tiles_out(0);
+    barrier();                                   // e1
+    barrier();                                   // e2
+    tiles_out(4);
+    barrier();                                   // e3
+  }
+}
+
 // ---- few columns (partial spectrum): one launch per WAVEFRONT of diamonds ------------------------------------------
 // k_bt2_apply gives a workgroup 16 NW columns and lets it walk all diamonds in order: with the ~100 columns of a
 // partial-spectrum solve that is two workgroups on the whole chip, each applying ~n^2 / 8192 diamonds one after the other
@@ -3358,6 +3682,26 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
                          d_sb_ws, SL, d_dia_off, d_z, stride_z, ncols, t);
     }
   } else {
+    // the role-split form (k_bt2_role: 64 columns per workgroup, MFMA / fragment / window-row waves): SPRINGCRAFT_BT2_ROLE = 1
+    static const int env_role = [] { const char* e = getenv("SPRINGCRAFT_BT2_ROLE"); return e ? atoi(e) : 0; }();
+    if (env_role != 0 && (n & 1) == 0 && batch >= 8 && n >= 256) {
+      static const bool role_attr = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_role), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kRoleLds) == hipSuccess;
+      }();
+      if (role_attr) {
+        const int nchunk64 = (ncols + 63) / 64;
+        hipLaunchKernelGGL(k_bt2_role, dim3((unsigned)(8 * ((batch + 7) / 8) * nchunk64)), dim3(768), kRoleLds, st, d_sb_ws, SL,
+                           d_dia_off, d_z, stride_z, ncols, batch);
+        SC_HIP(ctx, hipGetLastError());
+        if (prof) {
+          SC_HIP(ctx, hipEventRecord(ev[1], st));
+          SC_HIP(ctx, hipEventSynchronize(ev[1]));
+          SC_HIP(ctx, hipEventElapsedTime(ms_fused, ev[0], ev[1]));
+        }
+        return SC_OK;
+      }
+    }
     // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
     // ring of three half-diamond fragment buffers + one 16 x 18 transposition tile per wave
     constexpr size_t lds = sizeof(double) * (3 * kHalfDoubles + 8 * 16 * 18);
