@@ -410,7 +410,7 @@ def bulge_compulsory_bytes(n):
 
 
 CHASE_COUNTERS = ("chase_launches", "chase_pair_launches", "chase_timeouts", "chase_resumed", "stepwise_chases",
-                  "gemm3_launches")
+                  "gemm3_launches", "panel_coop_launches", "panel_coop_timeouts")
 
 
 def chase_form(before, after):

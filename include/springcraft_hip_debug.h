@@ -79,6 +79,14 @@ int sc_dbg_pair_stamps(unsigned long long* out16);
  * "chase_timeouts").  tests/test_two_stage_gpu.py */
 int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after);
 
+/* Cooperative panel QR of this context (k_panel_coop: several workgroups of one launch own 256 rows of a panel each;
+ * stage 1 of the two-stage tridiagonalisation, few matrices): min_rows = panels of at least that many rows take it
+ * (>= 128; the default rule: 300 rows with fewer than four matrices, else above the single-workgroup kernels' 6144),
+ * 0 = never, -1 = the default rule
+ * (SPRINGCRAFT_QR_COOP / SPRINGCRAFT_QR_COOP_MIN).  Counters "panel_coop_launches" / "panel_coop_timeouts".
+ * tests/test_two_stage_gpu.py */
+int sc_dbg_set_panel_coop(sc_ctx* ctx, int min_rows);
+
 #ifdef __cplusplus
 }
 #endif

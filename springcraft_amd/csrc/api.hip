@@ -400,6 +400,8 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   else if (k == "chase_pair_fallbacks") *value = ctx->cnt_pair_fallbacks;
   else if (k == "xcd_count") *value = ctx->nxcd;
   else if (k == "gemm3_launches") *value = ctx->cnt_gemm3_launches;
+  else if (k == "panel_coop_launches") *value = ctx->cnt_coop_launches;
+  else if (k == "panel_coop_timeouts") *value = ctx->cnt_coop_timeouts;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
   else if (k == "chase_incomplete") *value = ctx->cnt_chase_incomplete;
   else if (k == "chase_resumed") *value = ctx->cnt_chase_resumed;
@@ -423,6 +425,13 @@ int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after) {
   ctx->chase_mode = mode;
   ctx->chase_give_up = give_up_after;
   if (mode >= 0) ctx->chase_ok = -1;
+  return SC_OK;
+}
+
+int sc_dbg_set_panel_coop(sc_ctx* ctx, int min_rows) {
+  if (!ctx || min_rows < -1 || (min_rows > 0 && min_rows < 128)) return SC_ERR_INVALID_ARG;
+  ctx->coop_min_rows = min_rows;
+  if (min_rows != 0) ctx->coop_ok = -1;
   return SC_OK;
 }
 

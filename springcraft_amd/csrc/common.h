@@ -70,6 +70,11 @@ struct sc_ctx {
   // 1 set), and the launches it took
   int gemm3_attr = -1;
   long long cnt_gemm3_launches = 0;
+  // k_panel_coop (twostage.hip): dynamic LDS attribute of this device (-1 not tried, 0 refused, 1 set); coop_ok = 0
+  // once a wait between its workgroups timed out (the context then keeps to the chunked panel launches)
+  int coop_attr = -1, coop_ok = -1;
+  int coop_min_rows = -1;   // debug entry sc_dbg_set_panel_coop: rows from which a panel takes it (0 never, -1 default rule)
+  long long cnt_coop_launches = 0, cnt_coop_timeouts = 0;
   // event counters since the context was created (sc_ctx_get_counter)
   long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
             cnt_chase_sweeps = 0, cnt_stepwise_chases = 0, cnt_pair_launches = 0;

@@ -39,6 +39,8 @@ constexpr int kDescKinds = 9;     // GEMM records per panel and matrix (stage 1)
 constexpr int kIb = SC_QR_IB;     // inner block of the blocked panel QR (columns whose reflectors are applied to the rest at once)
 constexpr int kEarly = (kIb + 2) / 2;   // column loads per thread that cover a launch of an inner block (kIb + 1 columns)
 
+typedef int v4i __attribute__((ext_vector_type(4)));   // a 16-byte record (early hand-off of the chase, the cooperative panel)
+
 struct HH {
   double beta, tau, scale;
 };
@@ -757,6 +759,325 @@ __global__ __launch_bounds__(NT) void k_panel_wg(double* __restrict__ a_all, lon
   }
 }
 
+// ---- tall panels of a FEW matrices: the panel QR by several workgroups of one launch -------------------------------
+// A panel of more than 4096 rows of one matrix (C5: up to 24 000; a single N = 2000 structure: 5 936) went through the
+// chunked launches above: 80 dependent launches of ~8-10 us per panel, 0.77 ms per panel whatever its height (C5: 288 ms
+// of a 1.45 s solve, a single n = 6000 solve: 52 of 190 ms).  One workgroup cannot take such a panel -- it would stream
+// it at the rate of one CU.  Here G = ceil(m / 256) workgroups own 256 rows each, FOR THE WHOLE PANEL: the rows sit in
+// LDS (64 columns x 256 rows = 131 KB), loaded once and never re-read from memory, the 8 columns of the inner block in
+// registers as in k_panel_wg, and every sum over the rows of the panel is an exchange of 16-byte RECORDS
+// {value, sequence number} between the workgroups: written and read as ONE access (global_store / global_load_dwordx4
+// with sc1: agent scope, coherent across the XCDs without any fence or cache write-back -- the value and the tag that
+// says it is this step's arrive together).  Same arithmetic as k_panel_wg (tail Gram row + pivot row per column, the
+// inner block's reflectors applied to the columns on its right as one block update), other reduction trees:
+//   * per column: wave partials -> LDS -> the workgroup's 8 sums (+ workgroup 0: the pivot row) as 16 records; every
+//     workgroup polls the records of all G workgroups (the four waves a quarter each), sums them in the same order;
+//   * per inner block: M = V^T P for the columns on the right (up to 8 x 56 values + the block's 8 x 8 Gram matrix) by
+//     threads that own a COLUMN and a quarter of the rows (no cross-lane reduction: the column stride of 257 doubles
+//     makes both the row-parallel and the column-parallel LDS access conflict-free); the sum over the workgroups in two
+//     hops (value i is summed by workgroup i mod G, which publishes the total), because all-to-all would be G x 8 KB
+//     of records per workgroup.
+// All G workgroups must be resident together (each waits for all others): G <= 128 and the launch rule keeps
+// matrices x G well below the number of CUs; a wait that runs into its bound (never expected: seconds) raises a flag that
+// every workgroup sees in its polls, the kernel ends, the host returns an error and the context does not use the kernel
+// again.  Sequence numbers are unique within a solve ((panel + 1) * 128 + step) and the records are zeroed per solve.
+constexpr int kCoopRows = 256;
+constexpr int kCoopLd = kCoopRows + 1;
+constexpr int kCoopMaxG = 128;
+constexpr int kCoopVals = 8 * kB;                 // values of one block exchange (M and the Gram matrix)
+constexpr size_t kCoopLdsBytes = sizeof(double) * ((size_t)kB * kCoopLd + kCoopRows * 8 + 8 * kB + 64 + 16 + kB + 128 + 2);
+// workspace of one matrix (16-byte records): column records [2][G][16] | block partials [G][512] | block totals [512]
+__host__ __device__ inline size_t coop_recs_per_matrix(int G) { return (size_t)2 * G * 16 + (size_t)G * kCoopVals + kCoopVals; }
+
+__device__ __forceinline__ void st16_agent(void* p, double v, int tag) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const v4i r = {(int)(unsigned)b, (int)(unsigned)(b >> 32), tag, 0};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ double rec_value(v4i r) {
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)r.y << 32) | (unsigned)r.x));
+}
+// one record, polled until it carries `want` (false: the abort flag is up or the bound was reached)
+__device__ __forceinline__ bool poll_rec(const v4i* p, int want, int* ctl, double* out) {
+  long spins = 0;
+  while (true) {
+    v4i r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    if (r.z == want) { *out = rec_value(r); return true; }
+    ++spins;
+    if ((spins & 63) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if (spins > (1L << 22)) {
+      // (what was waited for, for the host's message: kind 2 = a block record, the tag wanted, the tag seen, the record)
+      if (atomicCAS(ctl, 0, 1) == 0) { ctl[1] = 2; ctl[2] = want; ctl[3] = r.z; ctl[4] = (int)(p - (const v4i*)nullptr); ctl[5] = blockIdx.x; }
+      return false;
+    }
+  }
+}
+// The 16 column records of the workgroups g = w, w + 4, ... (wave w): lane = (g / 4 mod 4) * 16 + value, R rounds of 16
+// workgroups; all loads of a poll in flight together.  Returns this wave's share of the 16 sums in lanes 0-15 (every lane
+// l holds the sum of value l & 15).
+template <int R>
+__device__ __forceinline__ bool poll_cols(const v4i* base, int G, int w, int lane, int want, int* ctl, double* out) {
+  const int v = lane & 15, q = lane >> 4;
+  const v4i* ptr[R];
+  bool need[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int g = w + 4 * (q + 4 * r);
+    need[r] = g < G;
+    ptr[r] = base + (size_t)(need[r] ? g : 0) * 16 + v;
+  }
+  v4i rec[R];
+  long spins = 0;
+  while (true) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rec[r]) : "v"(ptr[r]) : "memory");
+    if constexpr (R == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[0])::"memory");
+    if constexpr (R == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[0]), "+v"(rec[1])::"memory");
+    if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2])::"memory");
+    if constexpr (R == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3])::"memory");
+    if constexpr (R == 6)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3]), "+v"(rec[4]), "+v"(rec[5])::"memory");
+    if constexpr (R == 8)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3]), "+v"(rec[4]), "+v"(rec[5]), "+v"(rec[6]), "+v"(rec[7])::"memory");
+    bool fresh = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) fresh = fresh && (!need[r] || rec[r].z == want);
+    if (__all(fresh)) break;
+    ++spins;
+    if ((spins & 63) == 0 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if (spins > (1L << 22)) {
+      if (lane == 0 && atomicCAS(ctl, 0, 1) == 0) { ctl[1] = 1; ctl[2] = want; ctl[3] = rec[0].z; ctl[4] = w; ctl[5] = blockIdx.x; }
+      return false;
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s += need[r] ? rec_value(rec[r]) : 0.0;
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  *out = s;
+  return true;
+}
+
+__global__ __launch_bounds__(kCoopRows) void k_panel_coop(double* __restrict__ a_all, long long stride_a,
+                                                          double* __restrict__ tri_all, TriLayout TL,
+                                                          double* __restrict__ sb_all, SbLayout SL, int j0, int G,
+                                                          v4i* __restrict__ recs_all, int* __restrict__ ctl, int seq_base) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* Pl = sm;                          // [kB][kCoopLd]  the workgroup's rows of the panel
+  double* Vl = Pl + kB * kCoopLd;           // [256][8]       the inner block's reflectors by row; then partial sums
+  double* Ms = Vl + kCoopRows * 8;          // [8][kB]        M, then W = T^T M
+  double* red = Ms + 8 * kB;                // [2][4][8]
+  double* piv = red + 64;                   // [2][8]
+  double* tauA = piv + 16;                  // [kB]           tau of every column (stored at the end)
+  double* tot4 = tauA + kB;                 // [2][4][16]
+  int* s_dead = reinterpret_cast<int*>(tot4 + 128);
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  const int g = blockIdx.x, mat = blockIdx.y;
+  double* A = a_all + (size_t)mat * stride_a;
+  double* tri = tri_all + (size_t)mat * TL.slab;
+  double* sb = sb_all + (size_t)mat * SL.slab;
+  v4i* colrec = recs_all + (size_t)mat * coop_recs_per_matrix(G);
+  v4i* mrec = colrec + (size_t)2 * G * 16;
+  v4i* trec = mrec + (size_t)G * kCoopVals;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* P = A + (size_t)j0 * n + r0;
+  const int row = g * kCoopRows + tid;      // my row of the panel
+  const bool ok = row < m;
+  const int rc = min(row, m - 1);
+  const int R = (G + 15) / 16;
+  typedef char __attribute__((address_space(1)))* gbp;
+  typedef double __attribute__((address_space(1)))* gdp;
+  typedef const double __attribute__((address_space(1)))* gdp_c;
+  auto off = [&](int rr) -> unsigned {
+    unsigned e = 8u * (unsigned)rr;
+    asm volatile("" : "+v"(e));
+    return e;
+  };
+  auto st = [&](double* colbase, int rr, double val) { *(gdp)((gbp)colbase + off(rr)) = val; };
+  if (tid == 0) *s_dead = 0;
+  for (int c = 0; c < kB; ++c) {
+    const double v = *(gdp_c)((gbp)(P + (size_t)c * n) + off(rc));
+    Pl[c * kCoopLd + tid] = ok ? v : 0.0;
+  }
+  lds_barrier();
+
+  for (int c0 = 0; c0 < kB; c0 += 8) {
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = Pl[(c0 + i) * kCoopLd + tid];
+    // ---- the inner block's 8 reflectors
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = c0 + jj;
+      const int pb = jj & 1;
+      double gr[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) gr[c] = (c >= jj && row > j) ? x[jj] * x[c] : 0.0;
+      const double gs = wave_reduce8(gr);
+      if (lane < 8) red[(pb * 4 + wv) * 8 + wave_reduce8_index(lane)] = gs;
+      if (row == j) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) piv[pb * 8 + c] = x[c];
+      }
+      lds_barrier();
+      if (wv == 0 && lane < 16) {
+        double val;
+        if (lane < 8) val = (red[(pb * 4 + 0) * 8 + lane] + red[(pb * 4 + 1) * 8 + lane]) + (red[(pb * 4 + 2) * 8 + lane] + red[(pb * 4 + 3) * 8 + lane]);
+        else val = g == 0 ? piv[pb * 8 + lane - 8] : 0.0;
+        st16_agent(colrec + ((size_t)pb * G + g) * 16 + lane, val, seq_base + 1 + j);
+      }
+      {
+        const v4i* base = colrec + (size_t)pb * G * 16;
+        double s = 0.0;
+        bool good;
+        switch (R) {
+          case 1: good = poll_cols<1>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+          case 2: good = poll_cols<2>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+          case 3: good = poll_cols<3>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+          case 4: good = poll_cols<4>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+          case 5: case 6: good = poll_cols<6>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+          default: good = poll_cols<8>(base, G, wv, lane, seq_base + 1 + j, ctl, &s); break;
+        }
+        if (lane < 16) tot4[(pb * 4 + wv) * 16 + lane] = s;
+        if (!good && lane == 0) *s_dead = 1;
+      }
+      lds_barrier();
+      if (*s_dead) return;
+      // the 16 totals: lane l < 16 of every wave adds the four waves' shares of value l, the others take them from that
+      // lane through scalar registers
+      double fin[8], pv[8];
+      {
+        const int l16 = lane & 15;
+        const double t = (tot4[(pb * 4 + 0) * 16 + l16] + tot4[(pb * 4 + 1) * 16 + l16]) +
+                         (tot4[(pb * 4 + 2) * 16 + l16] + tot4[(pb * 4 + 3) * 16 + l16]);
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tb, c);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), c);
+          const double val = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+          if (c < 8) fin[c] = val; else pv[c - 8] = val;
+        }
+      }
+      const HH h = householder(pv[jj], fin[jj]);
+      if (tid == 0) tauA[j] = h.tau;
+      const double v = row > j ? h.scale * x[jj] : (row == j ? 1.0 : 0.0);
+#pragma unroll
+      for (int c = jj + 1; c < 8; ++c) {
+        const double wc = h.tau * (pv[c] + h.scale * fin[c]);
+        x[c] -= v * wc;
+      }
+      // column j is final.  It stays in LDS in the form the matrix takes it (R entries above the pivot, beta at it, v below);
+      // NOTHING is stored to memory inside the loop: a poll waits for vmcnt(0), i.e. for every store of the wave in flight
+      Pl[j * kCoopLd + tid] = row > j ? v : (row == j ? h.beta : x[jj]);
+      x[jj] = ok ? v : 0.0;
+    }
+    const int jn = c0 + 8;
+    if (jn >= kB) break;
+    const int ncols = kB - c0;               // the block's own columns (their Gram matrix) + the columns on the right
+    const int nvals = 8 * ncols;
+    const int blk = c0 >> 3;
+    // ---- V by row (for the broadcast reads below; the block's own columns -- their Gram matrix -- are read from here too)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Vl[tid * 8 + i] = x[i];
+    lds_barrier();
+    // ---- M[i][c] = v_i . P[:, c] over this workgroup's rows: thread = (column, quarter of the rows)
+    {
+      const int c = tid & 63, q = tid >> 6;
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < ncols) {
+        const double* vr = Vl + q * 64 * 8;
+        const double* pc = c < 8 ? vr + c : Pl + (c0 + c) * kCoopLd + q * 64;
+        const int stp = c < 8 ? 8 : 1;
+#pragma unroll 4
+        for (int rr = 0; rr < 64; ++rr) {
+          const double pval = pc[rr * stp];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += vr[rr * 8 + i] * pval;
+        }
+      }
+      lds_barrier();                        // (the partial sums take the place of V by row)
+      if (c < ncols) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Vl[(q * 64 + c) * 8 + i] = acc[i];
+      }
+    }
+    lds_barrier();
+    for (int idx = tid; idx < nvals; idx += kCoopRows) {
+      const double t = (Vl[idx] + Vl[64 * 8 + idx]) + (Vl[2 * 64 * 8 + idx] + Vl[3 * 64 * 8 + idx]);
+      st16_agent(mrec + (size_t)g * kCoopVals + idx, t, seq_base + 65 + blk);
+    }
+    lds_barrier();
+    // ---- hop 1: value idx is summed by workgroup idx mod G
+    bool good = true;
+    const int nown = g < nvals ? (nvals - g + G - 1) / G : 0;
+    for (int pi = tid; pi < nown * G; pi += kCoopRows) {
+      const int k = pi / G, gg = pi - k * G;
+      double val = 0.0;
+      good = poll_rec(mrec + (size_t)gg * kCoopVals + (g + k * G), seq_base + 65 + blk, ctl, &val) && good;
+      Vl[pi] = val;
+    }
+    if (!good) *s_dead = 1;
+    lds_barrier();
+    if (*s_dead) return;
+    for (int k = tid; k < nown; k += kCoopRows) {
+      double acc = 0.0;
+      for (int gg = 0; gg < G; ++gg) acc += Vl[k * G + gg];
+      st16_agent(trec + (g + k * G), acc, seq_base + 73 + blk);
+    }
+    // ---- hop 2: the totals
+    for (int idx = tid; idx < nvals; idx += kCoopRows) {
+      double val = 0.0;
+      good = poll_rec(trec + idx, seq_base + 73 + blk, ctl, &val) && good;
+      Ms[(idx & 7) * kB + c0 + (idx >> 3)] = val;
+    }
+    if (!good) *s_dead = 1;
+    lds_barrier();
+    if (*s_dead) return;
+    // W = T^T M for the columns on the right (as in k_panel_wg): one thread per column, in place
+    if (tid >= jn && tid < kB) {
+      double wcol[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double acc = Ms[i * kB + tid];
+#pragma unroll
+        for (int l = 0; l < i; ++l) acc -= Ms[l * kB + c0 + i] * wcol[l];
+        wcol[i] = tauA[c0 + i] * acc;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Ms[i * kB + tid] = wcol[i];
+    }
+    lds_barrier();
+    // P[:, c] -= V W[:, c] on my row
+    for (int c = jn; c < kB; ++c) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += x[i] * Ms[i * kB + c];
+      Pl[c * kCoopLd + tid] -= s2;
+    }
+    // (the next block reads its own row of Pl; Ms is still being read here by slower waves when a fast one is through
+    // the next block's first barriers and writes it again: one barrier)
+    lds_barrier();
+  }
+  // ---- the panel -> memory: the matrix' columns, and V in its explicit form into the three panel buffers
+  lds_barrier();
+  if (g == 0 && tid < kB) tri[TL.tau + j0 + tid] = tauA[tid];
+  if (ok) {
+    for (int c = 0; c < kB; ++c) {
+      const double val = Pl[c * kCoopLd + tid];
+      const double v = row > c ? val : (row == c ? 1.0 : 0.0);
+      st(P + (size_t)c * n, row, val);
+      st(sb + SL.vw + (size_t)c * n + r0, row, v);
+      st(sb + SL.wv + (size_t)(kB + c) * n + r0, row, -v);   // (-[W|V])
+      st(sb + SL.xv + (size_t)(2 * kB + c) * n + r0, row, v);
+    }
+  }
+}
+
 // X1 / X2 = sum of their K slices (split-K SYMM, few matrices): blockIdx.y = column of [X1 | X2], rows r0 .. n - 1
 __global__ __launch_bounds__(256) void k_sum_xslices(double* __restrict__ sb_all, SbLayout SL, int r0) {
   const int n = SL.n, p = SL.symm_split;
@@ -1143,7 +1464,6 @@ constexpr int kChaseCtlInts = 32;
 // 16-byte access.  A reader that finds a later tag knows that its task (s - 1, k + 1) is long complete and takes the
 // entry from the band instead.
 constexpr int kEarlyRing = 8;
-typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16(void* p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ v4i ld16_l2(const void* p) {
   v4i r;
@@ -3327,6 +3647,37 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const size_t lds_blk_b = sizeof(double) * ((size_t)kB * (kQrRows + 1) + kIb * kB + 4 * kB);
   static const bool blocked_qr = getenv("SPRINGCRAFT_QR_UNBLOCKED") == nullptr;
   PhaseTimer t_qr(ctx, "panel_qr", st), t_symm(ctx, "symm", st), t_syr2k(ctx, "syr2k", st), t_bulge(ctx, "bulge", st);
+  // ---- the cooperative panel kernel (k_panel_coop) for tall panels of a few matrices: SPRINGCRAFT_QR_COOP = 0 keeps the
+  // chunked launches, SPRINGCRAFT_QR_COOP_MIN = rows from which a panel takes it (default: above k_panel_wg's 4096)
+  static const int env_coop = [] { const char* e = getenv("SPRINGCRAFT_QR_COOP"); return e ? atoi(e) : 1; }();
+  // (one matrix, per panel: 0.77 ms by the chunked launches whatever the height, 0.3 - 0.5 ms by k_panel_wg's single
+  // workgroup, 0.25 - 0.3 ms here -- C5: panel QR 289 -> 109 ms, a single n = 6000 matrix: 52 -> 23 ms.  With four and more
+  // matrices the single-workgroup kernels run them side by side and keep their range; the taller panels come here)
+  static const int coop_min_env = [] { const char* e = getenv("SPRINGCRAFT_QR_COOP_MIN"); return e ? std::max(2 * kB, atoi(e)) : 0; }();
+  const int coop_min_few = ctx->coop_min_rows > 0 ? ctx->coop_min_rows : (coop_min_env > 0 ? coop_min_env : 300);
+  const int coop_min_many = ctx->coop_min_rows > 0 ? ctx->coop_min_rows : (coop_min_env > 0 ? coop_min_env : 12 * 512 + 1);
+  const int coop_min = std::min(coop_min_few, coop_min_many);
+  // every workgroup of a launch waits for all others: matrices x workgroups stays well below the CUs of the device
+  const int coop_budget = ctx->num_cus * 3 / 4;
+  const int coop_gmax = (std::max(n - kB, 1) + kCoopRows - 1) / kCoopRows;
+  v4i* coop_recs = nullptr;
+  int* coop_ctl = nullptr;
+  bool coop_used = false;
+  if ((ctx->coop_min_rows > 0 || (ctx->coop_min_rows < 0 && env_coop != 0)) && ctx->coop_ok != 0 && n - kB >= coop_min &&
+      coop_gmax <= kCoopMaxG) {
+    if (ctx->coop_attr < 0)
+      ctx->coop_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_coop),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLdsBytes) == hipSuccess;
+    const int nb_max = std::min(batch, coop_budget / coop_gmax);
+    if (ctx->coop_attr == 1 && nb_max >= 1) {
+      const size_t rec_bytes = (size_t)batch * coop_recs_per_matrix(coop_gmax) * sizeof(v4i);
+      SC_TRY(sc_reserve_dc_aux(ctx, 256 + rec_bytes));
+      coop_ctl = reinterpret_cast<int*>(ctx->dc_aux);
+      coop_recs = reinterpret_cast<v4i*>(reinterpret_cast<char*>(ctx->dc_aux) + 256);
+      // (sequence numbers are unique within a solve only)
+      SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, 256 + rec_bytes, st));
+    }
+  }
   // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, the trailing update
   // its role asks for (single: SYR2K; first of a pair: the next panel's columns only; second: the joint update).
   auto run_panel = [&](int p, int lo, int hi, hipStream_t ps, bool timed) -> int {
@@ -3356,7 +3707,16 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // (not for a few matrices: one workgroup streams its panel at the rate of ONE CU -- a single N = 2000 structure's
     // panel QRs take 70 instead of 52 ms that way)
     const bool use_wg512 = nr == kB && !use_wg && m <= 12 * 512 && env_wg != 0 && env_wg != 1 && nb >= 4;
-    if (use_wg) {
+    const int coop_g = (m + kCoopRows - 1) / kCoopRows;
+    const bool use_coop = coop_recs != nullptr && nr == kB && m >= (nb < 4 ? coop_min_few : coop_min_many) &&
+                          nb * coop_g <= coop_budget && ps == st;
+    if (use_coop) {
+      hipLaunchKernelGGL(k_panel_coop, dim3((unsigned)coop_g, (unsigned)nb), dim3(kCoopRows), kCoopLdsBytes, ps, a_h, stride_a,
+                         tri_h, TL, sb_h, SQ, j0, coop_g, coop_recs + (size_t)lo * coop_recs_per_matrix(coop_g), coop_ctl,
+                         (p + 1) * 128);
+      coop_used = true;
+      ++ctx->cnt_coop_launches;
+    } else if (use_wg) {
       const size_t lds_wg = sizeof(double) * (size_t)(2 * kWgWaves * 8 + 16 + 8 + 8 * kB + kWgWaves * kB * 8);
       const int ru = (m + kWgThreads - 1) / kWgThreads;
       const dim3 g1((unsigned)nb), b1((unsigned)kWgThreads);
@@ -3449,6 +3809,21 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     for (int p = 0; p < npanels; ++p) SC_TRY(run_panel(p, 0, batch, st, true));
   }
   SC_HIP(ctx, hipGetLastError());
+  if (coop_used) {
+    // a wait of k_panel_coop that ran into its bound (never expected: its workgroups were not resident together for
+    // seconds): the factorisation is not to be trusted -- an error, and this context keeps to the chunked launches
+    int h_flag[8] = {0};
+    SC_HIP(ctx, hipMemcpyAsync(h_flag, coop_ctl, sizeof(h_flag), hipMemcpyDeviceToHost, st));
+    SC_HIP(ctx, hipStreamSynchronize(st));
+    if (h_flag[0]) {
+      ctx->coop_ok = 0;
+      ++ctx->cnt_coop_timeouts;
+      ctx->err = "cooperative panel QR: a wait between its workgroups timed out (kind " + std::to_string(h_flag[1]) +
+                 ", tag wanted " + std::to_string(h_flag[2]) + ", seen " + std::to_string(h_flag[3]) + ", at " +
+                 std::to_string(h_flag[4]) + ", workgroup " + std::to_string(h_flag[5]) + ")";
+      return SC_ERR_NOCONV;
+    }
+  }
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
 
   // ---- stage 2

@@ -266,6 +266,56 @@ def test_persistent_chase_and_resume(n, batch, give_up, form):
         ctx.close()
 
 
+@pytest.mark.parametrize("n,batch,min_rows", [(700, 1, 128), (1030, 3, 200), (2101, 2, 128), (4700, 1, -1)])
+def test_cooperative_panel_qr(n, batch, min_rows):
+    """
+    Stage 1 with the cooperative panel kernel (k_panel_coop: the workgroups of one launch own 256 rows of a panel each
+    and exchange their sums as 16-byte records), forced down to short panels through the debug entry -- 3 to 9 workgroups
+    per matrix, several matrices per launch, an odd order -- and by the default rule on one n = 4700 matrix (panels of
+    300 rows and more: 19 workgroups -- two rounds of records per poll -- down to 2).  The counters say the kernel ran and no wait timed out; every member:
+    residual, orthogonality, eigenvalues against LAPACK.
+    """
+    import ctypes as C
+    import os
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    if min_rows < 0 and (os.environ.get("SPRINGCRAFT_QR_COOP") == "0" or os.environ.get("SPRINGCRAFT_QR_COOP_MIN")):
+        pytest.skip("the default rule is overridden (tools/test_matrix.sh)")
+    L = _hip.lib()
+    L.sc_dbg_set_panel_coop.restype = C.c_int
+    L.sc_dbg_set_panel_coop.argtypes = [C.c_void_p, C.c_int]
+    rs = np.random.RandomState(11 + n + batch)
+    mats = np.stack([sym(rs, n) for _ in range(batch)])
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_two_stage(True)
+        ctx.check(L.sc_dbg_set_panel_coop(ctx.handle, min_rows))
+        a = torch.from_numpy(mats.copy()).cuda()
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(v.data_ptr())))
+        ctx.synchronize()
+        lo = (300 if batch < 4 else 6145) if min_rows < 0 else min_rows
+        expected = sum(1 for p in range(n // 64 + 1) if n - (p + 1) * 64 >= max(lo, 65))
+        assert ctx.counter("panel_coop_launches") == expected and expected > 0, (ctx.counter("panel_coop_launches"), expected)
+        assert ctx.counter("panel_coop_timeouts") == 0
+        am = torch.from_numpy(mats).cuda()
+        eye = torch.eye(n, dtype=torch.float64, device="cuda")
+        for b in range(batch):
+            r = am[b] @ v[b].T - v[b].T * w[b][None, :]
+            assert float(r.abs().max()) <= 1e-10 * float(w[b].abs().max()), b
+            assert float((v[b] @ v[b].T - eye).abs().max()) <= 1e-11, b
+        for b in sorted({0, batch - 1}):
+            w_ref = np.linalg.eigvalsh(mats[b])
+            assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.close()
+
+
 def test_chase_by_size_rule_counts(sc):
     """The automatic rule: a latency-bound batch takes the persistent chase, and the counters say it completed."""
     import os

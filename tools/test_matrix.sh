@@ -30,3 +30,6 @@ run SPRINGCRAFT_GEMM3=2 SPRINGCRAFT_GEMM3_LOWER=1
 run SPRINGCRAFT_GEMM3=2 SPRINGCRAFT_GEMM3_ORDER=0 SPRINGCRAFT_GEMM3_W=0
 run SPRINGCRAFT_BULGE_NO_EARLY=1 SPRINGCRAFT_BULGE_PAIR=0
 run SPRINGCRAFT_BULGE_PERSISTENT=2 SPRINGCRAFT_BULGE_PAIR=0 SPRINGCRAFT_BULGE_NO_EARLY=1
+run SPRINGCRAFT_QR_COOP=0
+run SPRINGCRAFT_QR_COOP_MIN=128
+run SPRINGCRAFT_BT2_ROLE=1
