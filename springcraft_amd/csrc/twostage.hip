@@ -3067,6 +3067,18 @@ __device__ __forceinline__ unsigned long long role_uni64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// (diagnostic build -DBT2_STAMPS -DBT2_ROLE_STAMPS: cycles of an MFMA wave per diamond -- slots 4 q: the MFMAs of quarter
+// q up to the barrier inside it (+ the tail of the quarter before), 4 q + 1: the wait in that barrier, 14: the tail of
+// quarter 3, 15: the slide; tools/bt2_role_stamps.py)
+#if defined(BT2_STAMPS) && defined(BT2_ROLE_STAMPS)
+#define ROLE_STAMP(i) BT2_STAMP(i)
+#define ROLE_STAMP_DECL BT2_STAMP_DECL
+#define ROLE_STAMP_WRITE BT2_STAMP_WRITE
+#else
+#define ROLE_STAMP(i)
+#define ROLE_STAMP_DECL
+#define ROLE_STAMP_WRITE
+#endif
 __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ sb_all, SbLayout SL,
                                                      const int* __restrict__ dia_off, double* __restrict__ z_all,
                                                      long long stride_z, int ncols, int batch) {
@@ -3142,6 +3154,12 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
 
   if (w >= 8) {
     // ------------------------------------------------------------------------------------------------- Z waves
+    // NO vector-ALU instruction in this wave's steady state: a helper wave's VALU instruction only issues when the MFMA
+    // wave of its SIMD leaves a gap, i.e. at that wave's next barrier -- the stamps of the first version showed the MFMA
+    // waves waiting 1 250 cycles per diamond for this wave, which was still computing lane addresses and predicates.  So:
+    // lane offsets are computed once per kernel, everything that changes goes into the scalar base, lanes are switched off
+    // by scalar writes of EXEC inside the asm statements, and only windows that reach below the matrix (the last one or two
+    // of a sweep group) take the general path.
     const int zw = w - 8;
     const int c0 = chunk * 64 + 16 * zw;                       // first of this wave's 16 columns
     double* z_mat = z_all + (size_t)mat * stride_z;
@@ -3149,25 +3167,45 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
     char* p_in0 = rl + kRoleRing + zw * kRoleImg;
     char* p_out = rl + kRoleRing + 8 * kRoleImg + zw * kRoleImg;
     const unsigned long long col8 = (unsigned long long)n * 8ull;
+    const int pos = lane & 31, jj = lane >> 5;
+    unsigned lane16 = (unsigned)pos * 16u;                                        // a pair of rows per lane
+    unsigned lane_st = (unsigned)((unsigned long long)jj * col8) + (unsigned)pos * 16u;   // stores: two columns per instruction
+    unsigned img_st = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p_out + (unsigned)(jj * kRoleCol + pos * 16);
+    asm volatile("" : "+v"(lane16), "+v"(lane_st), "+v"(img_st));
     // rows row0 .. row0 + 63 of the 16 columns -> image `which` (lanes 0-31: rows row0 + 2 l, + 1 of one column per
-    // instruction; M0 = the middle of the image; rows beyond the matrix re-read its last pair and are put right by fix_rows)
-#define ROLE_DMA(J, IMM)                                                                                                     \
-  {                                                                                                                          \
-    const unsigned long long b_ = (unsigned long long)(size_t)z_mat +                                                       \
-                                  (unsigned long long)min(c0 + (J), ncols - 1) * col8 - (unsigned long long)(long long)(IMM);  \
-    asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #IMM : : "v"(voff), "s"(b_) : "memory");               \
-  }
+    // instruction; M0 = the middle of the image)
+    // (one instruction per column; the scalar base moves on by a column less the 528 bytes that the immediate grows by.
+    // The base is an in-out operand of the asm statement: hipcc then cannot compute the sixteen bases ahead -- it did, kept
+    // them across the diamond loop, ran out of scalar registers and reloaded them with v_readlane, a VALU instruction)
+#define ROLE_DMA(J, IMM)                                                                                      \
+  asm volatile("s_mov_b32 exec_hi, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %0 offset:" #IMM                \
+               "\n\ts_mov_b32 exec_hi, -1" : "+s"(b_) : "v"(vo) : "memory");                                   \
+  b_ += (c0 + (J) + 1 < nc) ? step : (unsigned long long)(-528ll);
+#define ROLE_DMA16                                                                                     \
+  ROLE_DMA(0, -3960) ROLE_DMA(1, -3432) ROLE_DMA(2, -2904) ROLE_DMA(3, -2376)                        \
+  ROLE_DMA(4, -1848) ROLE_DMA(5, -1320) ROLE_DMA(6, -792) ROLE_DMA(7, -264)                          \
+  ROLE_DMA(8, 264) ROLE_DMA(9, 792) ROLE_DMA(10, 1320) ROLE_DMA(11, 1848)                            \
+  ROLE_DMA(12, 2376) ROLE_DMA(13, 2904) ROLE_DMA(14, 3432) ROLE_DMA(15, 3960)
     auto fetch_rows = [&](int row0, int which) {
-      const int rr = min(row0 + 2 * (lane & 31), n - 2);
-      const unsigned voff = (unsigned)rr * 8u;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(img_in0 + (unsigned)(which * 4 * kRoleImg) + 3960u) : "memory");
-      if (lane < 32) {
-        ROLE_DMA(0, -3960) ROLE_DMA(1, -3432) ROLE_DMA(2, -2904) ROLE_DMA(3, -2376)
-        ROLE_DMA(4, -1848) ROLE_DMA(5, -1320) ROLE_DMA(6, -792) ROLE_DMA(7, -264)
-        ROLE_DMA(8, 264) ROLE_DMA(9, 792) ROLE_DMA(10, 1320) ROLE_DMA(11, 1848)
-        ROLE_DMA(12, 2376) ROLE_DMA(13, 2904) ROLE_DMA(14, 3432) ROLE_DMA(15, 3960)
+      int nc = ncols;
+      asm volatile("" : "+s"(nc));
+      const unsigned long long step = col8 - 528ull;
+      if (row0 + 64 <= n) {
+        // all 64 rows exist: the row goes into the scalar base; lanes 32-63 are off inside each asm statement (EXEC is
+        // whole again at its end: the compiler knows nothing of the change and may place its own instructions in between)
+        unsigned long long b_ = (unsigned long long)(size_t)z_mat + (unsigned long long)row0 * 8ull +
+                                (unsigned long long)min(c0, nc - 1) * col8 + 3960ull;
+        const unsigned vo = lane16;
+        ROLE_DMA16
+      } else {
+        // (rows beyond the matrix re-read its last pair and are put right by fix_rows)
+        unsigned long long b_ = (unsigned long long)(size_t)z_mat + (unsigned long long)min(c0, nc - 1) * col8 + 3960ull;
+        const unsigned vo = (unsigned)min(row0 + 2 * pos, n - 2) * 8u;
+        ROLE_DMA16
       }
     };
+#undef ROLE_DMA16
 #undef ROLE_DMA
     // (after the rows have landed) what lies below the matrix reads as zero; a pair that straddles the last row was read
     // one row early: its second value is the last row
@@ -3183,26 +3221,35 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
         }
       }
     };
-    // image out -> rows row0 .. row0 + 63 of the 16 columns, two columns per instruction: scalar base of the column pair +
-    // one lane offset, the predicates (rows / columns that exist) once per call
+    // image out -> rows row0 .. row0 + 63 of the 16 columns, two columns per instruction: all eight reads first, then
+    // the stores with the scalar base of the column pair (+ the row).  Windows inside the matrix and waves whose 16 columns
+    // all exist -- all but the last one or two windows of a sweep group and the last column chunk -- store without any
+    // predicate; the others take plain predicated stores.  (Switching lanes off by writing EXEC inside the asm statement,
+    // as the row fetch does, gave wrong results for the stores: tools/r05_role_dbg.sh, dbg 0 against dbg 1.)
     auto store_rows = [&](int row0) {
       typedef double d2z __attribute__((ext_vector_type(2)));
-      const int jj = lane >> 5, pos = lane & 31;
-      const int r = row0 + 2 * pos;
-      unsigned img_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p_out + (unsigned)(jj * kRoleCol + pos * 16);
-      asm volatile("" : "+v"(img_a));
-      const __attribute__((address_space(3))) char* img = (const __attribute__((address_space(3))) char*)(size_t)img_a;
-      const unsigned voff = (unsigned)((unsigned long long)jj * col8) + (unsigned)r * 8u;
-      const bool full = r + 1 < n, half = r + 1 == n;
+      const __attribute__((address_space(3))) char* img = (const __attribute__((address_space(3))) char*)(size_t)img_st;
+      d2z vv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const d2z v = *(const __attribute__((address_space(3))) d2z*)(img + 2 * i * kRoleCol);
-        const unsigned long long b = (unsigned long long)(size_t)z_mat + (unsigned long long)(c0 + 2 * i) * col8;
-        const bool col_ok = c0 + 2 * i + jj < ncols;
-        if (full && col_ok) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(b) : "memory");
-        if (half && col_ok) {
-          const double lo = v[0];
-          asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(lo), "s"(b) : "memory");
+      for (int i = 0; i < 8; ++i) vv[i] = *(const __attribute__((address_space(3))) d2z*)(img + 2 * i * kRoleCol);
+      __builtin_amdgcn_sched_barrier(0);
+      int nc = ncols;
+      asm volatile("" : "+s"(nc));
+      if (row0 + 64 <= n && c0 + 16 <= nc) {
+        unsigned long long b = (unsigned long long)(size_t)z_mat + (unsigned long long)c0 * col8 + (unsigned long long)row0 * 8ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %1, %2, %0\n\ts_nop 1" : "+s"(b) : "v"(lane_st), "v"(vv[i]) : "memory");
+          b += 2ull * col8;
+        }
+      } else {
+        const int r = row0 + 2 * pos;
+        for (int i = 0; i < 8; ++i) {
+          double* dst = z_mat + (size_t)(c0 + 2 * i + jj) * n + r;
+          if (c0 + 2 * i + jj < nc) {
+            if (r + 1 < n) { dst[0] = vv[i][0]; dst[1] = vv[i][1]; }
+            else if (r + 1 == n) dst[0] = vv[i][0];
+          }
         }
       }
     };
@@ -3216,8 +3263,8 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
       fix_rows(win0 + 64, 1);
       barrier();   // b0: both halves of the window are in the images
       barrier();   // b1: the MFMA wave has read them
-      // E_k = the rows that enter after diamond k (rows win_k + 128 ..), read by the MFMA wave at the end of diamond k out of
-      // image k & 1; fetched a whole diamond earlier
+      // E_k = the rows that enter after diamond k (rows win_k + 128 ..), read by the MFMA wave during the last quarter of
+      // diamond k out of image k & 1; fetched more than a diamond earlier
       if (1 < nk) fetch_rows(win0 + 128, 0);
       for (int k = 0; k < nk; ++k) {
         const int win = win0 + 64 * k;
@@ -3227,8 +3274,10 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
         if (k + 1 < nk) fix_rows(win + 128, k & 1);
         if (k > 0) store_rows(win - 64);
         barrier();   // quarter 2
-        barrier();   // quarter 3: at its end the MFMA wave reads E_k
-        if (k + 2 < nk) fetch_rows(win + 192, (k + 1) & 1);   // E_{k+1} into the image that was read a diamond ago
+        // E_{k+1} into the image that the MFMA wave read a diamond ago.  Here, not behind the barrier of quarter 3: the
+        // slide that follows that one is the busiest moment of the LDS
+        if (k + 2 < nk) fetch_rows(win + 192, (k + 1) & 1);
+        barrier();   // quarter 3: the MFMA wave reads E_k
       }
       const int winl = win0 + 64 * (nk - 1);
       barrier();   // e0
@@ -3246,45 +3295,81 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
   // this lane's place in a window image: column fr, row fk (+ 16 per tile, + 4 per register)
   char* q_in0 = rl + kRoleRing + w * kRoleImg + fr * kRoleCol + fk * 8;
   char* q_out = q_in0 + 8 * kRoleImg;
-  // The window: eight accumulator tiles (128 rows x 16 columns), ONE copy of the code.  (k_bt2_apply keeps three arrays of
-  // four tiles and three code phases so that the slide is a renaming; with the 168 registers of a 12-wave workgroup hipcc
-  // moved accumulator tuples through scratch where the phases join -- 44 spills per three diamonds, each reload a wait
-  // for memory in the MFMA stream: 1 130 ms.  Here the slide is 16 register moves per diamond: the finished rows go to
-  // the image out right behind the diamond's last MFMA, the lower half moves up, the entering rows land in its place.)
+  // The window: eight accumulator tiles (128 rows x 16 columns) in ONE array.  Diamonds alternate between two code PHASES:
+  // logical tile t of the window is zz[(t + 4 * phase) & 7], so the slide -- the upper half leaves, the lower half becomes
+  // the upper, 64 new rows enter below -- moves no register: the four tiles that leave are written to the image out and the
+  // entering rows are read into the same registers, which are the lower half of the next phase.  (k_bt2_apply rotates
+  // three arrays of four tiles through three phases; with the 168 registers of a 12-wave workgroup hipcc moved accumulator
+  // tuples through scratch where those phases join: 1 130 ms.  Version 3 kept one phase and moved 16 registers per
+  // diamond: 645 ms.)
   d4 zz[8];
+  ROLE_STAMP_DECL
+  // fragment registers: two rings of eight that alternate from quarter to quarter.  The barrier that opens quarter q + 1
+  // sits INSIDE quarter q, behind its 36th MFMA: by then every fragment of quarter q is in registers (its buffer may be
+  // overwritten), the first eight fragments of quarter q + 1 are requested right behind the barrier, and the last four
+  // MFMAs of quarter q cover their way from LDS -- no MFMA waits at a quarter's start.
+  double fa[8], fb[8];
   typedef double d2l __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) char* lcp;
-  // One quarter-diamond = one mini (st = 3 - QI): 20 MFMAs of W = V^T Z, 20 of Z -= (V T) W, fragments at `ring`.
-  auto quarter = [&](auto QI, const char* ring) {
-    constexpr int st = 3 - decltype(QI)::value;
-    // (addresses re-materialised at the point of use: hoisted out of the loops every "base + constant" becomes a register of
-    // its own; opaque here, the constants go into the LDS instructions' offset fields)
+  auto frag_ptr = [&](const char* ring) {
+    // (opaque: the constants below go into the LDS instructions' offset fields instead of registers of their own)
     unsigned ring_a = (unsigned)(size_t)(lcp)ring + (unsigned)lane * 16u;
     asm volatile("" : "+v"(ring_a));
-    const __attribute__((address_space(3))) d2l* ldsP = (const __attribute__((address_space(3))) d2l*)(size_t)ring_a;
+    return (const __attribute__((address_space(3))) d2l*)(size_t)ring_a;
+  };
+  auto first_frags = [&](const char* ring, double (&f)[8]) {
+    const __attribute__((address_space(3))) d2l* lp = frag_ptr(ring);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const d2l t = lp[j * 64];
+      f[2 * j] = t[0];
+      f[2 * j + 1] = t[1];
+    }
+  };
+  // One quarter-diamond = one mini (st = 3 - QI): 20 MFMAs of W = V^T Z, 20 of Z -= (V T) W, fragments at `ring`; `more`:
+  // another quarter follows in this sweep group (its fragments at `next_ring`).
+  // the 64 rows that enter at the next slide: read tile by tile during quarter 3 (four reads behind its MFMAs 1, 9, 17, 25)
+  d4 ze[4];
+  auto quarter = [&](auto QI, auto PH, const char* ring, const char* next_ring, double (&cur)[8], double (&nxt)[8],
+                     const char* enter) {
+    // (no "another quarter follows" flag: the last quarter of a sweep group does the same -- its barrier is the first of the
+    // group's epilogue, e0, and the fragments and rows it reads ahead are simply not used.  With a branch around the barrier
+    // and the reads, hipcc joined the two paths' pending-read counts conservatively and made MFMA 36 wait for the fragments
+    // of the NEXT quarter; with a second copy of the diamond for "no successor" it moved accumulator tuples through
+    // scratch: 301 spills)
+    constexpr bool more = true;
+    constexpr int st = 3 - decltype(QI)::value;
+    constexpr int ph4 = 4 * decltype(PH)::value;
+    const __attribute__((address_space(3))) d2l* ldsP = frag_ptr(ring);
     d4 wa = d4{0, 0, 0, 0};
     constexpr int kAhead = 8;
-    double fq[kAhead];
-#pragma unroll
-    for (int j = 0; j < kAhead / 2; ++j) {
-      const d2l t = ldsP[j * 64];
-      fq[2 * j] = t[0];
-      fq[2 * j + 1] = t[1];
-    }
 #pragma unroll
     for (int p = 0; p < kMiniFrags; ++p) {
-      const double a = fq[p % kAhead];
+      const double a = cur[p % kAhead];
       if (p < 20) {
-        const int rt = st + p / 4, r = p % 4;
+        const int rt = (st + p / 4 + ph4) & 7, r = p % 4;
         wa = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zz[rt][r], p == 0 ? d4{0, 0, 0, 0} : wa, 0, 0, 0);
       } else {
-        const int jj = p - 20, r = jj / 5, rt = st + jj % 5;
+        const int jj = p - 20, r = jj / 5, rt = (st + jj % 5 + ph4) & 7;
         zz[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wa[r], zz[rt], 0, 0, 0);
       }
       if ((p & 1) && p + kAhead - 1 < kMiniFrags) {
         const d2l t = ldsP[((p + kAhead - 1) / 2) * 64];
-        fq[(p - 1) % kAhead] = t[0];
-        fq[p % kAhead] = t[1];
+        cur[(p - 1) % kAhead] = t[0];
+        cur[p % kAhead] = t[1];
+      }
+      if (decltype(QI)::value == 3 && more && (p & 7) == 1 && p < 32) {
+        unsigned img_a = (unsigned)(size_t)(lcp)enter;
+        asm volatile("" : "+v"(img_a));
+        lcp img = (lcp)(size_t)img_a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ze[p >> 3][r] = *(const __attribute__((address_space(3))) double*)(img + (16 * (p >> 3) + 4 * r) * 8);
+      }
+      if (p == 35 && more) {
+        ROLE_STAMP(4 * decltype(QI)::value)
+        barrier();                    // quarter q + 1 starts (the last fragment reads of this one were issued at p = 31)
+        ROLE_STAMP(4 * decltype(QI)::value + 1)
+        first_frags(next_ring, nxt);
       }
       __builtin_amdgcn_sched_barrier(0);   // (the order as written: fragment reads a few MFMAs ahead, not all at once)
     }
@@ -3312,6 +3397,21 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // the slide behind a diamond of phase PH: tile by tile, the finished rows to the image out, the entering rows E_k (read
+  // into `ze` during quarter 3: all four MFMA waves slide at the same moment, and 64 KB of window rows + the fragments
+  // of the next quarter + the rows the Z waves fetch through the LDS in one burst took 1 480 cycles) into the same registers
+  auto slide = [&](int base) {
+    unsigned out_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)q_out;
+    asm volatile("" : "+v"(out_a));
+    __attribute__((address_space(3))) char* qo = (__attribute__((address_space(3))) char*)(size_t)out_a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(__attribute__((address_space(3))) double*)(qo + (16 * i + 4 * r) * 8) = zz[base + i][r];
+      zz[base + i] = ze[i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
@@ -3322,38 +3422,37 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
     tiles_in(0, q_in0);
     tiles_in(4, q_in0 + 4 * kRoleImg);
     barrier();                 // b1
+    barrier();                 // the group's first quarter starts (all later quarters: inside their predecessor)
+    first_frags(rl, fa);
     int buf = 0;               // 4 k % 3: the ring buffer of the diamond's first quarter
-#pragma clang loop unroll(disable)
-    for (int k = 0; k < nk; ++k) {
+    auto diamond = [&](auto PH, int k) {
+      constexpr int base = 4 * decltype(PH)::value;     // registers of the logical tiles 0 .. 3
       const char* r0 = rl + buf * kQuarterBytes;
       const char* r1 = rl + (buf + 1 > 2 ? buf - 2 : buf + 1) * kQuarterBytes;
       const char* r2 = rl + (buf + 2 > 2 ? buf - 1 : buf + 2) * kQuarterBytes;
-      barrier();
-      quarter(I0{}, r0);
-      barrier();
-      quarter(I1{}, r1);
-      barrier();
-      quarter(I2{}, r2);
-      barrier();
-      quarter(I3{}, r0);                         // (4 k + 3) % 3 = 4 k % 3
-      if (k + 1 < nk) {
-        // the slide: the finished rows into the image out (the Z wave stores them during the next diamond), the lower half
-        // of the window up, E_k -- the rows that enter -- into its place
-        tiles_out(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) zz[i] = zz[4 + i];
-        tiles_in(4, q_in0 + (k & 1) * 4 * kRoleImg);
-      }
-      buf = buf == 2 ? 0 : buf + 1;   // 4 (k + 1) % 3 = (4 k + 1) % 3
+      quarter(I0{}, PH, r0, r1, fa, fb, nullptr);
+      quarter(I1{}, PH, r1, r2, fb, fa, nullptr);
+      quarter(I2{}, PH, r2, r0, fa, fb, nullptr);  // (4 k + 3) % 3 = 4 k % 3
+      quarter(I3{}, PH, r0, r1, fb, fa, q_in0 + (k & 1) * 4 * kRoleImg);   // 4 (k + 1) % 3 = (4 k + 1) % 3
+      ROLE_STAMP(14)
+      if (k + 1 < nk) slide(base);
+      ROLE_STAMP(15)
+      buf = buf == 2 ? 0 : buf + 1;
+    };
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < nk; k += 2) {
+      diamond(I0{}, k);
+      if (k + 1 < nk) diamond(I1{}, k + 1);
     }
-    // the window of the last diamond goes back to memory
-    barrier();                                   // e0: the image out is free
-    tiles_out(0);
+    // the window of the last diamond goes back to memory (its phase: (nk - 1) & 1); e0 -- the image out is free -- was the
+    // barrier inside the last quarter
+    if ((nk - 1) & 1) tiles_out(4); else tiles_out(0);
     barrier();                                   // e1
     barrier();                                   // e2
-    tiles_out(4);
+    if ((nk - 1) & 1) tiles_out(0); else tiles_out(4);
     barrier();                                   // e3
   }
+  ROLE_STAMP_WRITE
 }
 
 // ---- few columns (partial spectrum): one launch per WAVEFRONT of diamonds ------------------------------------------
