@@ -99,7 +99,7 @@ def pmc_traffic(kind, n, batch):
     FETCH_SIZE and WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes).  Returned only when the
     passes were collected at exactly this matrix order AND batch; None otherwise (no extrapolation).
     """
-    names = {"bt2": ["r03_bt2_pmc_fetch_write.json"], "symv": ["r02_symv_pmc_fetch_size.json", "r01_symv_pmc_fetch_size.json"]}
+    names = {"bt2": ["r05_bt2_pmc_fetch_write.json", "r03_bt2_pmc_fetch_write.json"], "symv": ["r02_symv_pmc_fetch_size.json", "r01_symv_pmc_fetch_size.json"]}
     for name in names[kind]:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:

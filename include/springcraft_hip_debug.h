@@ -59,6 +59,11 @@ int sc_dbg_two_stage(sc_ctx* ctx, const double* a, int n, double* band_out, doub
  * out[64 workgroups][8 waves][16 sums + diamond count].  tools/bt2_stamps.py */
 int sc_dbg_bt2_stamps(unsigned long long* out);
 
+/* Shader clock while the most recent k_bt2_apply / k_bt2_role launch ran (library built with -DBT2_CLOCK; returns 1
+ * otherwise): out2 = {shader cycles (s_memtime), 100 MHz ticks (s_memrealtime)} over the life of wave 0 of workgroup 0.
+ * tools/bt2_clock.py */
+int sc_dbg_bt2_clock(unsigned long long* out2);
+
 /* s_memtime in front of every MFMA of one diamond of k_bt2_apply (library built with -DBT2_TRACE; returns 1 otherwise):
  * out[8 waves][2 halves][81].  tools/bt2_trace.py */
 int sc_dbg_bt2_trace(unsigned long long* out);

@@ -52,7 +52,8 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
 // Two-stage tridiagonalisation (twostage.hip) instead of the one-stage panel algorithm.  The one-stage SYMV streams
 // 4/3 n^3 bytes per matrix and is bandwidth-bound as soon as a few matrices are in flight; the two-stage path does its
 // O(n^3) work in MFMA GEMMs but pays ~3 n short launches and twice the back-transformation flops.  Measured crossover
-// on MI355X: batch * n^2 above ~ max(2e7, 1e4 n) (round 2: 5e7 + 6.7e3 n, round 1: 1.2e8; profiles/r0*_two_stage_crossover.txt).
+// on MI355X: batch * n^2 above ~ max(1.7e7, 5e3 n) (round 4: max(2e7, 1e4 n), round 2: 5e7 + 6.7e3 n, round 1: 1.2e8;
+// profiles/r0*_two_stage_crossover.txt).
 // sc_ctx_set_two_stage(ctx, 1 / 0) or SPRINGCRAFT_TWO_STAGE=1 / 0 force it on / off.
 bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
   static const int env_mode = [] {
@@ -67,7 +68,10 @@ bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
   // with two workgroups per CU and the secular solver of round 3 moved it down again): n = 6000 from 2 matrices (a tie
   // there), 3000 from 4, 1500 from ~8, 1026 and 513 with large batches (513 x 256: 49 vs 63 ms); one matrix at a time
   // stays on the one-stage path up to n ~ 12000 (n = 6000: 192 vs 237 ms, 3000: 67 vs 82)
-  return n >= 512 && (double)batch * n * n >= std::max(2.0e7, 1.0e4 * n);
+  // round 5 (profiles/r05_two_stage_crossover.txt; the panel QR of a few matrices by several workgroups of one launch,
+  // k_panel_coop): one matrix ties at n = 4500 (124 vs 122 ms) and n = 6000 (191 vs 187), two-stage from there on (7500:
+  // 310 vs 273, 9000: 441 vs 360, 12000: 856 vs 581); 2 x 4500: 157 vs 133, 8 x 1500: 43.5 vs 39.5
+  return n >= 512 && (double)batch * n * n >= std::max(1.7e7, 5.0e3 * n);
 }
 
 struct Plan {

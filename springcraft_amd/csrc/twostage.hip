@@ -2419,6 +2419,24 @@ __device__ unsigned long long g_bt2_stamps[64 * 8 * 17];
 #define BT2_STAMP(i)
 #define BT2_STAMP_WRITE
 #endif
+// Diagnostic build (-DBT2_CLOCK): the shader clock while k_bt2_apply / k_bt2_role run -- wave 0 of workgroup 0 reads
+// s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end (sc_dbg_bt2_clock, tools/bt2_clock.py).
+#ifdef BT2_CLOCK
+__device__ unsigned long long g_bt2_clk[2];
+#define BT2_CLOCK_BEGIN                                                                                      \
+  unsigned long long ck0_ = 0, rt0_ = 0;                                                                     \
+  if (blockIdx.x == 0 && threadIdx.x < 64)                                                                   \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0_), "=s"(rt0_)::"memory");
+#define BT2_CLOCK_END                                                                                        \
+  if (blockIdx.x == 0 && threadIdx.x < 64) {                                                                 \
+    unsigned long long ck1_, rt1_;                                                                           \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck1_), "=s"(rt1_)::"memory"); \
+    if (threadIdx.x == 0) { g_bt2_clk[0] = ck1_ - ck0_; g_bt2_clk[1] = rt1_ - rt0_; }                        \
+  }
+#else
+#define BT2_CLOCK_BEGIN
+#define BT2_CLOCK_END
+#endif
 // Diagnostic build (-DBT2_TRACE): s_memtime in front of every MFMA of ONE diamond (workgroup 0, sweep group
 // ngroups / 2, fourth chase position), every wave: g_bt2_trace[wave][half][step] (sc_dbg_bt2_trace, tools/bt2_trace.py).
 #ifdef BT2_TRACE
@@ -2808,6 +2826,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   bool have_fin = false;
 
   BT2_STAMP_DECL
+  BT2_CLOCK_BEGIN
   int S_cur = 0;   // (read by the -DBT2_TRACE build only)
   (void)S_cur;
   auto diamond = [&](auto PH, const double* fgrp, int k, int nh, bool more, int& slot, int win) {
@@ -3030,6 +3049,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
   }
   asm volatile("s_mov_b32 m0, %0" : : "s"(m0_keep));
   BT2_STAMP_WRITE
+  BT2_CLOCK_END
 }
 
 // ================================================================================================================
@@ -3038,9 +3058,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 // transposition / masks / stores of the window rows -- and every one of their memory and vector instructions costs the
 // SIMD's matrix pipe time (the pipes are busy 0.79 of that launch).  Here
 //   * waves 0-3 are one MFMA wave per SIMD, 16 columns each (a workgroup = 64 columns of one matrix): the 128-row window
-//     in three arrays of four accumulator tiles that rotate through three code phases exactly as in k_bt2_apply, 160
-//     MFMAs per diamond from ready-made fragments in LDS -- and nothing else but LDS reads / writes: the 64 rows that enter
-//     the window at a slide are read from an LDS image in accumulator layout, the 64 finished rows are written to one;
+//     in eight accumulator tiles that alternate between two code phases (see below), 160 MFMAs per diamond from
+//     ready-made fragments in LDS -- and nothing else but LDS reads / writes: the 64 rows that enter the window at a slide
+//     are read from an LDS image in accumulator layout, the 64 finished rows are written to one;
 //   * waves 4-7 stream the fragments a quarter-diamond (one mini: 20 KB, five 1-KB pieces per wave behind ONE write of
 //     M0) at a time into a ring of three quarter buffers, two quarters ahead;
 //   * waves 8-11 (one per MFMA wave) move the window rows: LDS-DMA of the entering rows, column by column (512 bytes per
@@ -3051,7 +3071,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_bt2_apply(const double* __restri
 // images) and four behind (they go out).  LDS: 3 x 20 KB + 3 x 4 x 8 448 B = 162 816 B.
 // (Version 1 -- ring of two half-diamond buffers, one image in, everything fetched one half ahead -- was correct and took
 // 999 ms per C3 step against k_bt2_apply's 605: a loader's two M0 groups per half land one after the other, and the
-// entering rows come from HBM: both sat on the critical path of every diamond.)
+// entering rows come from HBM: both sat on the critical path of every diamond.  Version 3, one barrier at the head of
+// every quarter: 645 ms; its stamps (profiles/r05_bt2_role_stamps.txt) showed the MFMA waves waiting 1 250 + 710 cycles
+// per diamond for the Z waves -- whose vector-ALU instructions only issue in the gaps the MFMA wave leaves -- and 1 480
+// cycles in the slide, when all four MFMA waves push 64 KB of window rows through the LDS at once.  This version: 614 ms
+// against 594, the same 12.2 k cycles per diamond and SIMD as k_bt2_apply -- 0.84 of the MFMA issue slots -- at the
+// 2.17 - 2.20 GHz both kernels run at, profiles/r05_bt2_clock.txt.  Not the default: SPRINGCRAFT_BT2_ROLE = 1.)
 // Image layout: column c of a wave's 16 at c * 528 B (64 rows + 16 B: an accumulator register's 16 columns x 2 rows fall
 // into 32 distinct 8-byte bank pairs).  Needs n even (the window starts at an odd row and moves in pairs of rows) --
 // bt2_batched checks.
@@ -3304,6 +3329,7 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
   // diamond: 645 ms.)
   d4 zz[8];
   ROLE_STAMP_DECL
+  BT2_CLOCK_BEGIN
   // fragment registers: two rings of eight that alternate from quarter to quarter.  The barrier that opens quarter q + 1
   // sits INSIDE quarter q, behind its 36th MFMA: by then every fragment of quarter q is in registers (its buffer may be
   // overwritten), the first eight fragments of quarter q + 1 are requested right behind the barrier, and the last four
@@ -3453,6 +3479,7 @@ __global__ __launch_bounds__(768, 1) void k_bt2_role(const double* __restrict__ 
     barrier();                                   // e3
   }
   ROLE_STAMP_WRITE
+  BT2_CLOCK_END
 }
 
 // ---- few columns (partial spectrum): one launch per WAVEFRONT of diamonds ------------------------------------------
@@ -4223,6 +4250,15 @@ extern "C" int sc_dbg_bt2_trace(unsigned long long* out) {
 }
 
 // ---- diagnostic build only: per-wave segment sums of k_bt2_apply (first 64 workgroups x 8 waves x (8 sums + count))
+extern "C" int sc_dbg_bt2_clock(unsigned long long* out2) {
+#ifdef BT2_CLOCK
+  return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_bt2_clk), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : 5;
+#else
+  (void)out2;
+  return 1;
+#endif
+}
+
 extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
 #ifdef BT2_STAMPS
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt2_stamps), sizeof(unsigned long long) * 64 * 8 * 17) == hipSuccess ? 0 : 5;

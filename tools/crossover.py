@@ -19,11 +19,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / 3 * 1e3:.1f}")
 '''
-for n_atoms, B in ((2000, 1), (2000, 2), (2000, 3), (2000, 4), (1000, 1), (1000, 4), (1000, 8), (1000, 16), (500, 8), (500, 16), (500, 32), (500, 64), (342, 64), (171, 256)):
+for n_atoms, B in ((4000, 1), (3000, 1), (2500, 1), (2000, 1), (2000, 2), (2000, 3), (2000, 4), (1500, 1), (1500, 2), (1000, 1), (1000, 4), (1000, 8), (1000, 16), (500, 8), (500, 16), (500, 32), (500, 64), (342, 64), (171, 256)):
     row = []
     for two in (0, 1):
         r = subprocess.run([sys.executable, "-c", code, str(n_atoms), str(B), str(two)], capture_output=True, text=True, timeout=300)
         row.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "fail")
     n = 3 * n_atoms
-    auto = "two" if (n >= 512 and B * n * n >= max(2.0e7, 1.0e4 * n)) else "one"   # eigh.hip:two_stage_for
+    auto = "two" if (n >= 512 and B * n * n >= max(1.7e7, 5.0e3 * n)) else "one"   # eigh.hip:two_stage_for
     print(f"N={n_atoms:5d} n={n:5d} B={B:3d}: one-stage {row[0]:>8s} ms   two-stage {row[1]:>8s} ms   (automatic: {auto}-stage)", flush=True)

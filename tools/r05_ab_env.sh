@@ -7,7 +7,7 @@ S=${3:-4}
 i=0
 for e in "$1" "$2" "$1" "$2"; do
   i=$((i+1))
-  env $e timeout -k 10 600 python bench.py --steps $S --warmup 2 > $O/bench_$i.json 2> $O/bench_$i.err; echo "[$e] rc $?"
+  env $e timeout -k 10 600 python bench.py --steps $S --warmup 2 --no-cpu-baseline > $O/bench_$i.json 2> $O/bench_$i.err; echo "[$e] rc $?"
   python - <<PY
 import json
 d=json.loads([l for l in open("$O/bench_$i.json") if l.startswith('{')][-1])

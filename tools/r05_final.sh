@@ -4,9 +4,11 @@
 #   bash tools/r05_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
 #                               runs) of k_bt2_apply -- bytes and MFMA-pipe occupancy at the benchmarked batch -- and the
 #                               MFMA-pipe occupancy of k_gemm3
-#   bash tools/r05_final.sh c1 | c2   the test matrix (tools/test_matrix.sh), in two halves
+#   bash tools/r05_final.sh c1 | c2 | c3   the test matrix (tools/test_matrix.sh), in three parts
 #   bash tools/r05_final.sh d   k_gemm3 beside k_gemm2 on the batched shapes of the step, the chase sweep with the points
-#                               beyond the round-4 range, per-phase stamps of k_bulge_chase at C4's shape
+#                               beyond the round-4 range, one-stage against two-stage over (N, batch)
+#   bash tools/r05_final.sh e   k_panel_coop on / off (C5, single-structure latencies); k_bt2_role beside k_bt2_apply on the
+#                               bench step, the stamps of its MFMA waves, the shader clock under both kernels
 # Everything lands in gpurun_out/r05_final/; what is to be judged is copied to profiles/r05_* (profiles/README.md).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -32,19 +34,29 @@ elif [ $part = b ]; then
   cp $(ls $OUT/prof/*kernel_stats.csv $OUT/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_bench.csv
   head -8 $OUT/rocprofv3_kernel_stats_bench.csv
   bash tools/pmc_kernel.sh k_bt2_apply r05_bt2 || exit 1
-  bash tools/pmc_mfma.sh k_bt2_apply r05_bt2 || exit 1
-  bash tools/pmc_mfma.sh k_gemm3 r05_gemm3 || exit 1
-  cp -r gpurun_out/pmc_r05_bt2 gpurun_out/pmc_r05_gemm3 $OUT/ 2>/dev/null
-elif [ $part = c1 ]; then
-  bash tools/test_matrix.sh 1 > $OUT/test_matrix_1.txt 2>&1
-  cat $OUT/test_matrix_1.txt
-elif [ $part = c2 ]; then
-  bash tools/test_matrix.sh 2 > $OUT/test_matrix_2.txt 2>&1
-  cat $OUT/test_matrix_2.txt
+  bash tools/pmc_mfma.sh k_bt2_apply r05_bt2 > $OUT/bt2_pmc_mfma.txt 2>&1 || exit 1
+  bash tools/pmc_mfma.sh k_gemm3 r05_gemm3 > $OUT/gemm3_pmc_mfma.txt 2>&1 || exit 1
+  grep -h run_mfma $OUT/bt2_pmc_mfma.txt $OUT/gemm3_pmc_mfma.txt | cut -c1-400
+  python3 tools/pmc_to_json.py gpurun_out/pmc_r05_bt2 k_bt2_apply 6000 64 > $OUT/bt2_pmc_fetch_write.json
+  grep -E "traffic_over|l2_hit|hbm_bytes" $OUT/bt2_pmc_fetch_write.json
+  python3 tools/pmc_summary.py gpurun_out/pmc_r05_bt2 > $OUT/bt2_pmc_summary.txt 2>&1
+elif [ $part = c1 ] || [ $part = c2 ] || [ $part = c3 ]; then
+  k=${part#c}
+  bash tools/test_matrix.sh $k 3 > $OUT/test_matrix_$k.txt 2>&1
+  cat $OUT/test_matrix_$k.txt
+elif [ $part = e ]; then
+  ENVS="SPRINGCRAFT_QR_COOP=0 SPRINGCRAFT_QR_COOP=1" bash tools/r05_coop.sh > $OUT/panel_coop_ab.txt 2>&1 || { tail -5 $OUT/panel_coop_ab.txt; exit 1; }
+  grep -v amdgpu.ids $OUT/panel_coop_ab.txt
+  bash tools/r05_ab_env.sh SPRINGCRAFT_BT2_ROLE=0 SPRINGCRAFT_BT2_ROLE=1 2 > $OUT/bt2_role_ab.txt 2>&1
+  cat $OUT/bt2_role_ab.txt
+  bash tools/r05_role_stamps.sh > /dev/null 2>&1; cp gpurun_out/r05_role/stamps.txt $OUT/bt2_role_stamps.txt; cat $OUT/bt2_role_stamps.txt
+  rm -f gpurun_out/r05_role/clock.txt; bash tools/r05_bt2_clock.sh > /dev/null 2>&1; cp gpurun_out/r05_role/clock.txt $OUT/bt2_clock.txt; cat $OUT/bt2_clock.txt
 else
   timeout -k 10 300 python tools/gemm3_shapes.py 32 2>&1 | grep -v amdgpu.ids | cut -c1-260 > $OUT/gemm3_shapes.txt
   cat $OUT/gemm3_shapes.txt
   timeout -k 10 500 python tools/bulge_sweep.py ext > $OUT/bulge_sweep_ext.txt 2>&1
   cat $OUT/bulge_sweep_ext.txt
+  timeout -k 10 400 python tools/crossover.py 2>&1 | grep -v amdgpu.ids > $OUT/two_stage_crossover.txt
+  cat $OUT/two_stage_crossover.txt
 fi
 echo "part $part done"

@@ -2,11 +2,12 @@
 # The eigensolver tests under every switch that selects an alternative code path (on the GPU box):  bash tools/test_matrix.sh
 set -u
 T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py"
-# (two halves, a gpurun call is limited to 20 minutes:  bash tools/test_matrix.sh 1 | 2; no argument: everything)
+# (in parts, a gpurun call is limited to 20 minutes:  bash tools/test_matrix.sh <part> [parts = 2]; no argument: everything)
 HALF=${1:-0}
+PARTS=${2:-2}
 K=0
 # (a failing row stays in the output with the names of the tests that failed: -rf prints them above the summary line)
-run() { K=$((K+1)); if [ $HALF -ne 0 ] && [ $((K % 2)) -ne $((HALF % 2)) ]; then return; fi; echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q -rf 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|error" | tail -4; }
+run() { K=$((K+1)); if [ $HALF -ne 0 ] && [ $((K % PARTS)) -ne $((HALF % PARTS)) ]; then return; fi; echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q -rf 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|error" | tail -4; }
 run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=1 SPRINGCRAFT_STAGE1_STREAMS=1
 run SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3
 run SPRINGCRAFT_BULGE_PERSISTENT=2
