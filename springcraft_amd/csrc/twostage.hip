@@ -3987,11 +3987,14 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const bool pair_attr = ctx->pair_attr == 1;
     const long long work = (long long)batch * n / 128;
     // SPRINGCRAFT_BULGE_PAIR = 0: never the pair form, 2: the pair form for every persistent chase (tests), else by size
-    static const long long kPairWorkMax = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR_MAX"); return e ? atoll(e) : 3200LL; }();
-    // (by size only inside the measured range, profiles/r04_bulge_sweep.txt: up to 64 x 6000.  Far beyond it an XCD holds
-    // more matrices than pair workgroups fit -- one workgroup then walks all pairs of a matrix in sequence --, a regime
-    // nobody has timed: there the older rule applies)
-    const bool pair_measured = work <= kPairWorkMax;
+    static const long long kPairWorkMax = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR_MAX"); return e ? atoll(e) : 6000LL; }();
+    // (by size only inside the measured range -- profiles/r04_bulge_sweep.txt up to 64 x 6000, profiles/r05_bulge_sweep_ext.txt
+    // up to 96 x 6000 and 256 x 3000, B n / 128 = 6000: the pair form wins everywhere there (622 vs 742 / 775 ms, 354 vs
+    // 467 / 558) -- and only while every matrix of an XCD has a pair workgroup of its own (one per CU): 512 x 1026 puts 64
+    // matrices on the 32 CUs of an XCD, a workgroup then walks the matrices one after the other, 687 ms against 110 by
+    // the per-wavefront launches.  ADVICE round 4.)
+    if (ctx->nxcd <= 0) SC_TRY(probe_xcd_count(ctx, st));
+    const bool pair_measured = work <= kPairWorkMax && (batch + ctx->nxcd - 1) / ctx->nxcd <= std::max(1, ctx->num_cus / ctx->nxcd);
     const bool pair = ctx->chase_form >= 0 ? (ctx->chase_form == 1 && pair_attr)
                                            : use_pair && pair_attr &&
                                                  (force_pair == 2 || (work > 1100 && batch >= 8 && pair_measured));
