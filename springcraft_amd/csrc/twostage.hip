@@ -3789,8 +3789,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   v4i* coop_recs = nullptr;
   int* coop_ctl = nullptr;
   bool coop_used = false;
+  // (only when the whole batch runs on one stream: the parts of a split batch must not be factored by different kernels --
+  // other reduction trees, other last bits -- or the same structure at two batch positions gives different eigenvalues)
+  static const int env_s1_early = [] { const char* e = getenv("SPRINGCRAFT_STAGE1_STREAMS"); return e ? atoi(e) : 0; }();
+  const bool one_stream = std::max(1, std::min(env_s1_early > 0 ? env_s1_early : ((batch >= 32 && !prof) ? 2 : 1), std::min(batch, 4))) == 1;
   if ((ctx->coop_min_rows > 0 || (ctx->coop_min_rows < 0 && env_coop != 0)) && ctx->coop_ok != 0 && n - kB >= coop_min &&
-      coop_gmax <= kCoopMaxG) {
+      coop_gmax <= kCoopMaxG && one_stream) {
     if (ctx->coop_attr < 0)
       ctx->coop_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_coop),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLdsBytes) == hipSuccess;

@@ -44,6 +44,14 @@ elif [ $part = c1 ] || [ $part = c2 ] || [ $part = c3 ]; then
   k=${part#c}
   bash tools/test_matrix.sh $k 3 > $OUT/test_matrix_$k.txt 2>&1
   cat $OUT/test_matrix_$k.txt
+elif [ $part = c4 ]; then
+  # the row that failed in part c2 (STAGE1_STREAMS=3: the part of the batch on the main stream was factored by k_panel_coop,
+  # the others by the single-workgroup kernels -- same structure, other last bits), after the fix (no k_panel_coop when the
+  # batch is split over streams)
+  T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py"
+  { echo "== (re-run after the fix) SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3";
+    SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3 timeout -k 10 600 python -m pytest $T -x -q -rf 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|error" | tail -4; } > $OUT/test_matrix_4.txt
+  cat $OUT/test_matrix_4.txt
 elif [ $part = e ]; then
   ENVS="SPRINGCRAFT_QR_COOP=0 SPRINGCRAFT_QR_COOP=1" bash tools/r05_coop.sh > $OUT/panel_coop_ab.txt 2>&1 || { tail -5 $OUT/panel_coop_ab.txt; exit 1; }
   grep -v amdgpu.ids $OUT/panel_coop_ab.txt
