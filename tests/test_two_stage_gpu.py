@@ -301,7 +301,10 @@ def test_cooperative_panel_qr(n, batch, min_rows):
         ctx.synchronize()
         lo = (300 if batch < 4 else 6145) if min_rows < 0 else min_rows
         expected = sum(1 for p in range(n // 64 + 1) if n - (p + 1) * 64 >= max(lo, 65))
-        assert ctx.counter("panel_coop_launches") == expected and expected > 0, (ctx.counter("panel_coop_launches"), expected)
+        assert expected > 0
+        if batch > 1 and int(os.environ.get("SPRINGCRAFT_STAGE1_STREAMS") or 0) > 1:
+            expected = 0   # a batch split over streams keeps to ONE panel kernel for all its parts (tools/test_matrix.sh)
+        assert ctx.counter("panel_coop_launches") == expected, (ctx.counter("panel_coop_launches"), expected)
         assert ctx.counter("panel_coop_timeouts") == 0
         am = torch.from_numpy(mats).cuda()
         eye = torch.eye(n, dtype=torch.float64, device="cuda")
