@@ -76,6 +76,10 @@ int sc_dbg_bulge_stamps(unsigned long long* out6);
  * out16[0..7] = cycles of thread 0 between the nine barriers of a step (wait, loads, E right update + reflector,
  * column sums, E left update + D products, w, D update, store drain), [8] = steps, [9] = steps with both teams at work. */
 int sc_dbg_pair_stamps(unsigned long long* out16);
+/* The same for the persistent chase with one sweep per workgroup (k_bulge_chase; library built with -DCHASE_STAMPS, else
+ * returns 1): out16[1..11] = cycles of all waves between eleven points of a task, summed over all tasks since the last call
+ * (the segments are listed at the macro in twostage.hip), [15] = waves x tasks.  tools/chase_stamps.py */
+int sc_dbg_chase_stamps(unsigned long long* out16);
 
 /* Persistent bulge chase of this context: mode -1 = SPRINGCRAFT_BULGE_PERSISTENT or the size rule (default), 0 never,
  * 1 by size, 2 always (3: always and in the pair form k_bulge_pair, 4: always with one sweep per workgroup,

@@ -1471,6 +1471,32 @@ __device__ __forceinline__ v4i ld16_l2(const void* p) {
   return r;
 }
 
+// Diagnostic build (-DCHASE_STAMPS): shader cycles of every wave of k_bulge_chase between ten points of a task, summed over
+// all tasks of all workgroups (sc_dbg_chase_stamps, tools/chase_stamps.py): [1] wait for the predecessor sweep (poll +
+// barrier), [2] loads of both blocks + first products up to the first barrier, [3] right update of E + the new reflector,
+// [4] column sums + u, [5] second wait (early hand-off), [6] E stores issued + D into LDS, [7] D products, [8] w, [9] D update
+// + stores issued, [10] store drain + barrier, [11] publish; [15] = waves x tasks.  Tasks at k = 0 have no E block: their
+// segments [2] .. [4] are the reflector of the column alone.
+#ifdef CHASE_STAMPS
+__device__ unsigned long long g_chase_stamps[16];
+#define CHASE_STAMP_DECL unsigned long long cs_prev = 0, cs_n = 0, cs_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CHASE_STAMP(i)                                                                 \
+  {                                                                                    \
+    unsigned long long t_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    if ((i) != 0) cs_sum[i] += t_ - cs_prev;                                           \
+    cs_prev = t_;                                                                      \
+  }
+#define CHASE_STAMP_WRITE                                                                          \
+  if ((threadIdx.x & 63) == 0) {                                                                   \
+    for (int i_ = 1; i_ < 12; ++i_) atomicAdd(&g_chase_stamps[i_], cs_sum[i_]);                    \
+    atomicAdd(&g_chase_stamps[15], cs_n);                                                          \
+  }
+#else
+#define CHASE_STAMP_DECL
+#define CHASE_STAMP(i)
+#define CHASE_STAMP_WRITE
+#endif
 __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W, int nxcd,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
                                                      int* __restrict__ ctl, int give_up_after, v4i* __restrict__ early) {
@@ -1498,6 +1524,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
   const int K0 = chase_len(n, 0);
   int tasks_left = give_up_after;
 
+  CHASE_STAMP_DECL
   int cur = slot % mpx, exhausted = 0;
   while (exhausted < mpx) {
     const int b = xcd + nxcd * cur;
@@ -1529,6 +1556,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         // beta from the record, the last row of the diagonal block after the second wait).  Else (mode 0): all of sweep
         // s - 1 that touches these rows is complete.
         const bool early_task = early != nullptr && s > 0 && k + 1 < len_prev;
+        CHASE_STAMP(0)
         if (tid == 0) {
           // (the stop flag and the predecessor's progress are requested TOGETHER: one L2 round trip, ~0.7 us, per task on
           // the sweep-to-sweep critical path instead of two; while waiting, the flag is looked at every 16th poll only)
@@ -1571,6 +1599,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         }
         __syncthreads();
         if (!s_go) return;
+        CHASE_STAMP(1)
         const int mode = s_mode;   // 1: the last row of both blocks is not in the band yet
         // second wait of a task that started on the record (mode 1): task (s - 1, k + 1) complete, then the last row of
         // the diagonal block.  Nothing of this task has been stored before.
@@ -1637,6 +1666,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             red[q * kB + i] = a;
           }
           lds_barrier();
+          CHASE_STAMP(2)
           {
             const double ui = tau_p * ((red[i] + red[kB + i]) + (red[2 * kB + i] + red[3 * kB + i]));
 #pragma unroll
@@ -1659,6 +1689,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             }
           }
           lds_barrier();
+          CHASE_STAMP(3)
           {
             double a = 0.0;
 #pragma unroll
@@ -1668,7 +1699,9 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           lds_barrier();
           if (tid < kB) u[tid] = s_tau * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
           lds_barrier();
+          CHASE_STAMP(4)
           CHASE_SECOND_WAIT()
+          CHASE_STAMP(5)
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
             const int jj = q * 16 + c;
@@ -1688,7 +1721,9 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             if (tid == 0) { s_tau = h.tau; s_beta = h.beta; }
           }
           lds_barrier();
+          CHASE_STAMP(4)
           CHASE_SECOND_WAIT()
+          CHASE_STAMP(5)
           if (tid < L) col_s[(unsigned)(1 + tid)] = tid == 0 ? s_beta : 0.0;
         }
 #undef CHASE_SECOND_WAIT
@@ -1710,6 +1745,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           }
         }
         lds_barrier();
+        CHASE_STAMP(6)
         {
           double a = 0.0;
 #pragma unroll
@@ -1717,6 +1753,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           red[q * kB + i] = a;
         }
         lds_barrier();
+        CHASE_STAMP(7)
         const double tau_now = s_tau;
         if (tid < 64) {
           const double pp = tau_now * ((red[tid] + red[kB + tid]) + (red[2 * kB + tid] + red[3 * kB + tid]));
@@ -1724,6 +1761,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           u[tid] = pp - 0.5 * tau_now * dot * vn[tid];
         }
         lds_barrier();
+        CHASE_STAMP(8)
         for (int jj = q * 16; jj < q * 16 + 16; ++jj)
           if (i >= jj && i < L)
             colbase_k[(unsigned)((i - jj) + jj * kLdab)] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
@@ -1731,8 +1769,10 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         if (tid == 0) sb[SL.tau2 + dia * kG + cc] = tau_now;
         tau_p = tau_now;
         // ---- publish: this task's stores are in the L2 before the counter moves
+        CHASE_STAMP(9)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        CHASE_STAMP(10)
         if (tid == 0) {
           __hip_atomic_store(prog + s, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (k + 1 == len) atomicAdd(ctl + 16 + xcd, 1);
@@ -1742,9 +1782,14 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             __hip_atomic_store(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        CHASE_STAMP(11)
+#ifdef CHASE_STAMPS
+        ++cs_n;
+#endif
       }
     }
   }
+  CHASE_STAMP_WRITE
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -4257,6 +4302,17 @@ extern "C" int sc_dbg_bt2_trace(unsigned long long* out) {
 }
 
 // ---- diagnostic build only: per-wave segment sums of k_bt2_apply (first 64 workgroups x 8 waves x (8 sums + count))
+extern "C" int sc_dbg_chase_stamps(unsigned long long* out16) {
+#ifdef CHASE_STAMPS
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chase_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 5;
+  static const unsigned long long zeros[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_chase_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 5;
+#else
+  (void)out16;
+  return 1;
+#endif
+}
+
 extern "C" int sc_dbg_bt2_clock(unsigned long long* out2) {
 #ifdef BT2_CLOCK
   return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_bt2_clk), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : 5;

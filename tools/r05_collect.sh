@@ -23,6 +23,7 @@ grep -h "^run_mfma" $F/gemm3_pmc_mfma.txt > $P/r05_gemm3_pmc_mfma.txt
 cp $F/gemm3_shapes.txt $P/r05_gemm3_shapes.txt
 cp $F/bulge_sweep_ext.txt $P/r05_bulge_sweep_ext.txt
 cp $F/two_stage_crossover.txt $P/r05_two_stage_crossover.txt
+cp $F/chase_stamps.txt $P/r05_chase_stamps.txt
 grep -v "amdgpu.ids" $F/panel_coop_ab.txt > $P/r05_panel_coop_ab.txt
 cp $F/bt2_role_ab.txt $P/r05_bt2_role_ab.txt
 cp $F/bt2_role_stamps.txt $P/r05_bt2_role_stamps.txt

@@ -6,7 +6,8 @@
 #                               MFMA-pipe occupancy of k_gemm3
 #   bash tools/r05_final.sh c1 | c2 | c3   the test matrix (tools/test_matrix.sh), in three parts
 #   bash tools/r05_final.sh d   k_gemm3 beside k_gemm2 on the batched shapes of the step, the chase sweep with the points
-#                               beyond the round-4 range, one-stage against two-stage over (N, batch)
+#                               beyond the round-4 range, one-stage against two-stage over (N, batch), per-phase stamps of
+#                               k_bulge_chase at the shapes of C4, C2 and one N = 2000 structure
 #   bash tools/r05_final.sh e   k_panel_coop on / off (C5, single-structure latencies); k_bt2_role beside k_bt2_apply on the
 #                               bench step, the stamps of its MFMA waves, the shader clock under both kernels
 # Everything lands in gpurun_out/r05_final/; what is to be judged is copied to profiles/r05_* (profiles/README.md).
@@ -66,5 +67,7 @@ else
   cat $OUT/bulge_sweep_ext.txt
   timeout -k 10 400 python tools/crossover.py 2>&1 | grep -v amdgpu.ids > $OUT/two_stage_crossover.txt
   cat $OUT/two_stage_crossover.txt
+  bash tools/r05_chase_stamps.sh > /dev/null 2>&1 || true
+  cat $OUT/chase_stamps.txt
 fi
 echo "part $part done"
