@@ -14,12 +14,16 @@ cp $F/bt2_pmc_fetch_write.json $P/r05_bt2_pmc_fetch_write.json
 cp $F/bt2_pmc_summary.txt $P/r05_bt2_pmc_summary.txt
 grep -h "^run_mfma" $F/bt2_pmc_mfma.txt > $P/r05_bt2_pmc_mfma.txt
 grep -h "^run_mfma" $F/gemm3_pmc_mfma.txt > $P/r05_gemm3_pmc_mfma.txt
-{ cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt | grep -v "^part"
-  echo "# The row that failed above (test_config3_batched_automatic_path: \"same structure at two batch positions must give"
-  echo "# identical eigenvalues\") did so because with SPRINGCRAFT_STAGE1_STREAMS=3 the part of the batch on the main stream was"
-  echo "# factored by k_panel_coop and the parts on the side streams by the single-workgroup panel kernels: both right, other"
-  echo "# reduction trees, other last bits.  Fix (twostage.hip): no k_panel_coop when the batch is split over streams.  Re-run:"
-  grep -v "^part" $F/test_matrix_4.txt; } > $P/r05_test_matrix.txt
+{ echo "# bash tools/r05_final.sh c1 | c2 | c3 (tools/test_matrix.sh in three parts) on the final build; 27 rows."
+  echo "# One row FAILED in the first run of the matrix this round (build of commit 'Pair chase by size: ...'):"
+  echo "#   == SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3"
+  echo "#   FAILED tests/test_batched_configs_gpu.py::test_config3_batched_automatic_path"
+  echo "#   1 failed, 138 passed, 2 skipped in 50.49s"
+  echo "# ('same structure at two batch positions must give identical eigenvalues'): with the batch split over three streams the"
+  echo "# part on the main stream was factored by k_panel_coop, the parts on the side streams by the single-workgroup panel"
+  echo "# kernels -- both right, other reduction trees, other last bits.  Fix (twostage.hip): no k_panel_coop when the batch is"
+  echo "# split over streams; test_cooperative_panel_qr follows that override.  The rows below are the re-run of ALL rows after it."
+  cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt | grep -v "^part"; } > $P/r05_test_matrix.txt
 cp $F/gemm3_shapes.txt $P/r05_gemm3_shapes.txt
 cp $F/bulge_sweep_ext.txt $P/r05_bulge_sweep_ext.txt
 cp $F/two_stage_crossover.txt $P/r05_two_stage_crossover.txt
