@@ -291,6 +291,12 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
  *   "stepwise_chases"  bulge chases that ran as per-wavefront launches from the start
  *   "chase_xcd_min" / "chase_xcd_max"   workgroups per XCD in the most recent persistent chase
  *   "chase_wait_matrix" / "_sweep" / "_task"   where the last timed-out wait stood (-1: never)
+ *   "chase_pair_fallbacks"   pair launches the device refused (dynamic LDS) and that were re-issued in the one-sweep form
+ *   "xcd_count"        XCDs of the device as a probe launch saw them (0: not probed yet)
+ *   "gemm3_launches"   launches the role-split persistent GEMM (k_gemm3) took
+ *   "panel_coop_launches"   panel factorisations by the cooperative kernel (k_panel_coop: several workgroups of one launch)
+ *   "panel_coop_timeouts"   of those, how many ran into the bound of a wait between its workgroups -- expected to stay 0;
+ *                      the solve returns SC_ERR_NOCONV and the context keeps to the chunked panel launches afterwards
  * Unknown names: SC_ERR_INVALID_ARG, *value = 0. */
 int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value);
 
