@@ -10,6 +10,7 @@ for c in c2 c4 c5; do line $F/bench_$c.json > $P/r05_bench_$c.json; done
 cp $F/latency.txt $P/r05_latency.txt
 cp $F/gputest_durations.txt $P/r05_gputest_durations.txt
 cp $F/rocprofv3_kernel_stats_bench.csv $P/r05_rocprofv3_kernel_stats_bench.csv
+[ -f $F/rocprofv3_kernel_stats_bench_c5.csv ] && cp $F/rocprofv3_kernel_stats_bench_c5.csv $P/r05_rocprofv3_kernel_stats_bench_c5.csv
 cp $F/bt2_pmc_fetch_write.json $P/r05_bt2_pmc_fetch_write.json
 cp $F/bt2_pmc_summary.txt $P/r05_bt2_pmc_summary.txt
 grep -h "^run_mfma" $F/bt2_pmc_mfma.txt > $P/r05_bt2_pmc_mfma.txt

@@ -4,6 +4,7 @@
 #   bash tools/r05_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
 #                               runs) of k_bt2_apply -- bytes and MFMA-pipe occupancy at the benchmarked batch -- and the
 #                               MFMA-pipe occupancy of k_gemm3
+#   bash tools/r05_final.sh b2  rocprofv3 kernel statistics of bench.py --config c5
 #   bash tools/r05_final.sh c1 | c2 | c3   the test matrix (tools/test_matrix.sh), in three parts
 #   bash tools/r05_final.sh d   k_gemm3 beside k_gemm2 on the batched shapes of the step, the chase sweep with the points
 #                               beyond the round-4 range, one-stage against two-stage over (N, batch), per-phase stamps of
@@ -41,6 +42,13 @@ elif [ $part = b ]; then
   python3 tools/pmc_to_json.py gpurun_out/pmc_r05_bt2 k_bt2_apply 6000 64 > $OUT/bt2_pmc_fetch_write.json
   grep -E "traffic_over|l2_hit|hbm_bytes" $OUT/bt2_pmc_fetch_write.json
   python3 tools/pmc_summary.py gpurun_out/pmc_r05_bt2 > $OUT/bt2_pmc_summary.txt 2>&1
+elif [ $part = b2 ]; then
+  # per-kernel totals of the C5 line (one n = 24 000 matrix, 106 modes): k_panel_coop among them
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o bench --output-format csv -- \
+     python3 $ROOT/bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_under_rocprof.json 2> $OUT/bench_c5_under_rocprof.err) || { tail -5 $OUT/bench_c5_under_rocprof.err; exit 1; }
+  rm -f $OUT/prof_c5/*kernel_trace.csv $OUT/prof_c5/*/*kernel_trace.csv
+  cp $(ls $OUT/prof_c5/*kernel_stats.csv $OUT/prof_c5/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_bench_c5.csv
+  head -12 $OUT/rocprofv3_kernel_stats_bench_c5.csv | cut -c1-220
 elif [ $part = c1 ] || [ $part = c2 ] || [ $part = c3 ]; then
   k=${part#c}
   bash tools/test_matrix.sh $k 3 > $OUT/test_matrix_$k.txt 2>&1
