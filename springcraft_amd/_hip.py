@@ -35,7 +35,7 @@ SC_FF_TABULATED = 3
 # every symbol include/springcraft_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "sc_ctx_create", "sc_ctx_create_on_stream", "sc_ctx_destroy", "sc_last_error",
-    "sc_ctx_synchronize", "sc_device_info", "sc_contacts", "sc_pairs", "sc_kirchhoff_f64",
+    "sc_ctx_synchronize", "sc_host_alloc", "sc_host_free", "sc_device_info", "sc_contacts", "sc_pairs", "sc_kirchhoff_f64",
     "sc_hessian_f64", "sc_kirchhoff_from_pairs_f64", "sc_hessian_from_pairs_f64", "sc_eigh_f64",
     "sc_anm_eigen_f64", "sc_gnm_eigen_f64", "sc_dev_kirchhoff_f64", "sc_dev_hessian_f64",
     "sc_dev_eigh_f64", "sc_eigh_workspace_bytes", "sc_ctx_set_profiling", "sc_last_eigh_timings",
@@ -151,6 +151,8 @@ def lib():
         "sc_ctx_destroy": (None, [vp]),
         "sc_last_error": (C.c_char_p, [vp]),
         "sc_ctx_synchronize": (i32, [vp]),
+        "sc_host_alloc": (i32, [C.c_size_t, P(vp)]),
+        "sc_host_free": (i32, [vp]),
         "sc_device_info": (i32, [vp, C.c_char_p, C.c_size_t]),
         "sc_contacts": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), vp, P(i64)]),
         "sc_pairs": (i32, [vp, vp, i64, P(FFDesc), P(PatchDesc), i64, vp, vp, P(i64)]),
@@ -320,7 +322,7 @@ class Modes:
 
     def eigen(self):
         w = np.empty(self.order)
-        v = np.empty((self.order, self.order))
+        v = host_array((self.order, self.order))
         self._ctx.check(self._L.sc_modes_get(self._h, ptr(w), ptr(v)))
         return w, v
 
@@ -381,6 +383,74 @@ def ptr(a):
         return None
     assert a.flags.c_contiguous
     return C.c_void_p(a.ctypes.data)
+
+
+# Result arrays on page-locked host memory.  A large result -- the (n, n) eigenvectors above all: 288 MB at N = 2000 --
+# crosses PCIe in 5 ms when its destination is page-locked and in 17-25 ms when it is fresh pageable memory
+# (tools/d2h_probe.py).  Allocating page-locked memory costs more than that (33 ms for 288 MB), so the blocks are pooled:
+# a NumPy array handed out here lives on a block from sc_host_alloc; when the array and all its views are gone, the
+# block goes back to the pool and serves the next result of that size.  Bounded on both ends: at most
+# ``_PIN_LIVE_MAX`` bytes handed out at a time (beyond that, and for small arrays, ordinary np.empty) and at most
+# ``_PIN_POOL_MAX`` bytes kept idle.  SPRINGCRAFT_PINNED_RESULTS=0 turns it off.
+_PIN_MIN = 8 << 20
+_PIN_LIVE_MAX = 3 << 30
+_PIN_POOL_MAX = 1 << 30
+_pin_free = {}          # bytes -> [address, ...]
+_pin_live = 0
+_pin_idle = 0
+_pin_lock = None
+
+
+def _pin_release(address, nbytes):
+    global _pin_live, _pin_idle
+    try:
+        with _pin_lock:
+            _pin_live -= nbytes
+            if _pin_idle + nbytes <= _PIN_POOL_MAX:
+                _pin_free.setdefault(nbytes, []).append(address)
+                _pin_idle += nbytes
+                return
+        _lib.sc_host_free(C.c_void_p(address))
+    except Exception:   # interpreter shutdown: the process' memory goes with it
+        pass
+
+
+def host_array(shape):
+    """A C-contiguous float64 array for a result that comes back from the device (see above)."""
+    global _pin_lock, _pin_live, _pin_idle
+    import threading
+    import weakref
+
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    count = int(np.prod(shape)) if shape else 1
+    nbytes = 8 * count
+    if nbytes < _PIN_MIN or os.environ.get("SPRINGCRAFT_PINNED_RESULTS", "1") == "0":
+        return np.empty(shape)
+    if _pin_lock is None:
+        _pin_lock = threading.Lock()
+    address = None
+    with _pin_lock:
+        if _pin_live + nbytes > _PIN_LIVE_MAX:
+            return np.empty(shape)
+        blocks = _pin_free.get(nbytes)
+        if blocks:
+            address = blocks.pop()
+            _pin_idle -= nbytes
+        _pin_live += nbytes
+    if address is None:
+        p = C.c_void_p()
+        try:
+            rc = lib().sc_host_alloc(nbytes, C.byref(p))
+        except Exception:
+            rc = 1
+        if rc != SC_OK or not p.value:
+            with _pin_lock:
+                _pin_live -= nbytes
+            return np.empty(shape)
+        address = p.value
+    block = (C.c_double * count).from_address(address)
+    weakref.finalize(block, _pin_release, address, nbytes)   # runs when the last array / view on the block is gone
+    return np.frombuffer(block, dtype=np.float64).reshape(shape)
 
 
 def make_ff_desc(kind, cutoff_distance):

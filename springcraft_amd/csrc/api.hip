@@ -350,6 +350,23 @@ void sc_ctx_destroy(sc_ctx* ctx) {
 
 const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int sc_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return SC_ERR_INVALID_ARG;
+  *out = nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return SC_ERR_NOMEM;
+  }
+  *out = p;
+  return SC_OK;
+}
+
+int sc_host_free(void* p) {
+  if (!p) return SC_OK;
+  return hipHostFree(p) == hipSuccess ? SC_OK : SC_ERR_HIP;
+}
+
 int sc_ctx_synchronize(sc_ctx* ctx) {
   if (!ctx) return SC_ERR_INVALID_ARG;
   SC_HIP(ctx, hipSetDevice(ctx->device));

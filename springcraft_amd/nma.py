@@ -49,7 +49,7 @@ def eigh(matrix, eigenvectors=True, subset_by_index=None):
         ctx.check(_hip.lib().sc_eigh_range_f64(ctx.handle, _hip.ptr(a), n, lo, hi, _hip.ptr(w), _hip.ptr(v)))
         return (w, v) if eigenvectors else w
     w = np.empty(n, dtype=np.float64)
-    v = np.empty((n, n), dtype=np.float64) if eigenvectors else None
+    v = _hip.host_array((n, n)) if eigenvectors else None
     ctx.check(_hip.lib().sc_eigh_f64(ctx.handle, _hip.ptr(a), n, _hip.ptr(w), _hip.ptr(v)))
     return (w, v) if eigenvectors else w
 

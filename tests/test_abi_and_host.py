@@ -253,3 +253,16 @@ def test_hip_sources_compile_without_warnings(tmp_path):
         if "warning" in r.stderr:
             out.append(f"{src}:\n{r.stderr}")
     assert not out, "\n".join(out)[-4000:]
+
+
+def test_host_array_without_a_device():
+    """Result arrays: small ones are ordinary NumPy arrays; large ones fall back to ordinary memory when the runtime cannot
+    page-lock (no GPU here) -- either way a writable C-contiguous float64 ndarray of the requested shape."""
+    from springcraft_amd import _hip
+
+    for shape in ((7,), (10, 10), (1100, 1100)):
+        a = _hip.host_array(shape)
+        assert isinstance(a, np.ndarray) and a.shape == shape and a.dtype == np.float64
+        assert a.flags.c_contiguous and a.flags.writeable
+        a[...] = 1.0
+        assert float(a.sum()) == float(np.prod(shape))
