@@ -339,13 +339,13 @@ class Modes:
     def dcc(self, mode_idx, norm):
         idx = self._index_list(mode_idx)
         n = self.order // self.dim
-        out = np.empty((n, n))
+        out = host_array((n, n))
         self._ctx.check(self._L.sc_modes_dcc(self._h, ptr(idx), len(idx), int(bool(norm)), ptr(out)))
         return out
 
     def prs(self, rcond, norm):
         n = self.order // 3
-        out = np.empty((n, n))
+        out = host_array((n, n))
         self._ctx.check(self._L.sc_modes_prs(self._h, float(rcond), int(bool(norm)), ptr(out)))
         return out
 

@@ -117,7 +117,7 @@ def _assemble(coord, force_field, dim, inv_sqrt_mass=None):
     w = None
     if inv_sqrt_mass is not None:
         w = np.ascontiguousarray(inv_sqrt_mass, dtype=np.float64)
-    matrix = np.empty((n * dim, n * dim), dtype=np.float64)
+    matrix = _hip.host_array((n * dim, n * dim))   # (large ones on pooled page-locked memory: the copy back is 3-5 x faster)
 
     if fused:
         pairs, _ = _pair_list(ctx, coord, ff_desc, patch_desc, want_sq_dist=False)

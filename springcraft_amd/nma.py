@@ -63,7 +63,7 @@ def pinvh(matrix, rcond=1e-6):
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
         raise ValueError(f"Expected a square matrix, got shape {a.shape}")
     n = a.shape[0]
-    out = np.empty((n, n), dtype=np.float64)
+    out = _hip.host_array((n, n))
     ctx = _hip.context()
     ctx.check(_hip.lib().sc_pinvh_f64(ctx.handle, _hip.ptr(a), n, float(rcond), _hip.ptr(out)))
     return out
