@@ -52,31 +52,104 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
   const int j = blockIdx.x;
   if (j >= m) return;
   const int k = il + j;
-  // (the recurrence is a chain of divisions; d and e come in chunks of 16 requested together, so that the chain waits
-  // for memory once per chunk instead of once per row)
+  // Sturm count WITHOUT a division in the chain (round 5).  The ratio form q_i = (d_i - x) - e_{i-1}^2 / q_{i-1} that
+  // dstebz uses is a chain of n IEEE divisions -- ~150 cycles each on this chip: 4 ms per count at n = 24 000, 68 ms for
+  // the 16 counts an eigenvalue needs.  The product form p_i = a_i p_{i-1} - b_i p_{i-2} (a_i = (d_i - x) s,
+  // b_i = (e_{i-1} s)^2, q_i = p_i / p_{i-1}) has ONE fused multiply-add in the chain (b_i p_{i-2} is known a step
+  // earlier); the eigenvalues below x are the sign changes of the sequence, as Wilkinson's bisection counted them.  The
+  // rows are scaled by s = 1 / (Gershgorin radius) so that |a_i| <= 2, b_i <= 1: a sequence grows by at most 3^8 between
+  // two re-normalisations (every 8 rows, by the exponent of the larger of the last two members).  An exact zero takes
+  // the sign opposite to its predecessor -- dstebz's q = -pivmin.
+  // The rows reach the chain through LDS: lane l of the wave loads row 64 c + l of a 64-row chunk c (two coalesced loads
+  // per chunk and lane instead of 2 x 64 loads of one address each), a group of four chunks ahead of the one in work; a
+  // chunk in work is written to LDS once (16 bytes per lane) and every step reads its row as ONE broadcast ds_read_b128.
+  // (History of the 68 ms this kernel took at n = 24 000: every lane loading every row in chunks of 16, the count waited for
+  // memory 1 500 times -- the division-free chain alone: 64 ms; rows from the lanes by v_readlane, four per step, with the
+  // wait states they need and a scalar branch per step for the tail: 42 ms.)
+  const double sc = 1.0 / fmax(span + 2.0 * emax, 1e-300);
+  const double tiny_p = 0x1p-900;
+  const int nchunk = (n + 63) / 64;
+  typedef double d2s __attribute__((ext_vector_type(2)));
+  __shared__ d2s rows[2][64];
+  auto load_rows = [&](int c, double& as, double& bs) {
+    const int i = min(c * 64 + lane, n - 1);
+    const double es = i > 0 ? e[i - 1] * sc : 0.0;
+    as = d[i] * sc;
+    bs = es * es;
+  };
+  auto hi32 = [](double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32); };
   auto count_below = [&](double x) {
-    int cnt = 0;
-    double q = d[0] - x;
-    if (fabs(q) < pivmin) q = -pivmin;
-    cnt += q < 0.0;
-    for (int i0 = 1; i0 < n; i0 += 16) {
-      double dd[16], ee[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int i = min(i0 + u, n - 1);
-        dd[u] = d[i];
-        ee[u] = e[i - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (i0 + u < n) {
-          q = dd[u] - x - ee[u] * ee[u] / q;
-          if (fabs(q) < pivmin) q = -pivmin;
-          cnt += q < 0.0;
-        }
-      }
+    const double xs = x * sc;
+    unsigned cnt = 0;
+    double p2 = 1.0, p1 = 1.0;           // p_{-1} (any: b_0 = 0), p_0 = 1
+    // one step: row (a, b) -> the next member of the sequence.  An exact zero (rare: a branch for the whole wave) takes a
+    // tiny value of the sign opposite to its predecessor, so that a decoupled block behind it (b = 0) starts afresh
+#define STURM_STEP(r)                                                                  \
+    {                                                                                  \
+      double p0 = fma((r)[0] - xs, p1, -((r)[1] * p2));                                \
+      if (__builtin_expect(__any(p0 == 0.0), 0))                                       \
+        if (p0 == 0.0) p0 = -copysign(tiny_p, p1);                                     \
+      cnt += (hi32(p0) ^ hi32(p1)) >> 31;                                              \
+      p2 = p1;                                                                         \
+      p1 = p0;                                                                         \
     }
-    return cnt;
+#define STURM_RENORM()                                                                 \
+    {                                                                                  \
+      int ex;                                                                          \
+      (void)frexp(fmax(fabs(p1), fabs(p2)), &ex);                                      \
+      p1 = ldexp(p1, -ex);                                                             \
+      p2 = ldexp(p2, -ex);                                                             \
+    }
+    // groups of four chunks: the rows of group g + 1 are requested at the top of group g and used a group (256 rows) later
+    // -- inside ONE loop body, so that the compiler's wait in front of their first use is the only one
+    const int ngroup = (nchunk + 3) / 4;
+    double ca[4], cb[4], na[4], nb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_rows(min(t, nchunk - 1), ca[t], cb[t]);
+    for (int g = 0; g < ngroup; ++g) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) load_rows(min(4 * (g + 1) + t, nchunk - 1), na[t], nb[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 4 * g + t;
+        const int lim = min(64, n - c * 64);      // (<= 0 behind the last chunk)
+        if (lim <= 0) break;
+        rows[t & 1][lane] = d2s{ca[t], cb[t]};
+        __builtin_amdgcn_wave_barrier();
+        if (lim == 64) {
+          // (the rows of the next eight steps are read while these eight run: one exposed LDS latency per step otherwise)
+          d2s r8[8], n8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r8[q] = rows[t & 1][q];
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk) {
+            if (blk < 7) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) n8[q] = rows[t & 1][8 * (blk + 1) + q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) STURM_STEP(r8[q])
+            STURM_RENORM()
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r8[q] = n8[q];
+          }
+        } else {
+          for (int u = 0; u < lim; ++u) {
+            const d2s r = rows[t & 1][u];
+            STURM_STEP(r)
+            if ((u & 7) == 7) STURM_RENORM()
+          }
+          STURM_RENORM()
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
+    }
+#undef STURM_STEP
+#undef STURM_RENORM
+    return (int)cnt;
   };
   double a = lo, b = hi;   // invariant: count_below(a) <= k < count_below(b)
   for (int round = 0; round < 16; ++round) {
@@ -111,7 +184,17 @@ __device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {
   return ((double)(x >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
 }
 
-// Workspace per matrix (doubles): u0,u1,u2,lm : 4 x n x m, piv (as double flags): n x m, all [row][vector].
+// Workspace per matrix: forward records F[row][vector] = {multiplier, 1.0 if rows k, k + 1 were swapped} (16 bytes) and
+// backward records B[row][vector] = {1 / pivot, u1 / pivot, u2 / pivot, -} (32 bytes): 6 n m doubles.
+// The passes over the factors are bound by memory LATENCY -- 106 vectors are two waves on the whole chip, every row of a
+// pass needs its record, and a wave can have 63 loads in flight: the records are requested a chunk of rows at a time and the
+// chunk is as long as that limit allows (28 rows forward, 20 backward; round 4: four arrays of doubles in chunks of 8 rows,
+// 3 000 exposed latencies per pass instead of 860 / 1 200: 66 -> 30 ms at n = 24 000).  The back substitution multiplies
+// by the reciprocal pivot that the factorisation stored: no division in its chain.
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int kSteinFw = 28, kSteinBw = 20, kSteinFac = 24;
+
 __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all, TriLayout TL, int m,
                                               const double* __restrict__ w_all, long long stride_w,
                                               double* __restrict__ fac_all, long long stride_fac,
@@ -121,20 +204,21 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
   const double* e = tri + TL.e;
   const int n = TL.n;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  // scale of T (the lanes strided over the rows, as in k_sturm_range: one lane walking all n rows waits for memory in
+  // every one of them) and a tiny separation of (numerically) coincident eigenvalues, as dstein does
+  double tnorm = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64)
+    tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, off));
+  if (tnorm == 0.0) tnorm = 1.0;
   if (j >= m) return;
   const double* w = w_all + (size_t)blockIdx.y * stride_w;
   double* fac = fac_all + (size_t)blockIdx.y * stride_fac;
-  double* u0 = fac;                          // pivots
-  double* u1 = fac + (size_t)n * m;          // first super-diagonal of U
-  double* u2 = fac + (size_t)2 * n * m;      // second super-diagonal of U
-  double* lm = fac + (size_t)3 * n * m;      // multipliers
-  double* pv = fac + (size_t)4 * n * m;      // 1.0 = rows k, k+1 were swapped
+  d2v* F = reinterpret_cast<d2v*>(fac);                              // [n][m]
+  d4v* B = reinterpret_cast<d4v*>(fac + (size_t)2 * n * m);          // [n][m]
   double* X = x_all + (size_t)blockIdx.y * stride_x + (size_t)j * n;   // column j of X (n x m, ld n)
 
-  // scale of T and a tiny separation of (numerically) coincident eigenvalues, as dstein does
-  double tnorm = 0.0;
-  for (int i = 0; i < n; ++i) tnorm = fmax(tnorm, fabs(d[i]) + (i < n - 1 ? fabs(e[i]) : 0.0) + (i > 0 ? fabs(e[i - 1]) : 0.0));
-  if (tnorm == 0.0) tnorm = 1.0;
   const double tiny = kEpsS * tnorm;
   double lam = w[j];
   {
@@ -143,32 +227,37 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
     for (int q = j - 1; q >= 0 && fabs(w[q] - w[q + 1]) <= 10.0 * tiny; --q) ++run;
     lam += run * 10.0 * tiny;
   }
-#define AT(arr, k) arr[(size_t)(k) * m + j]
+#define FAT(k) F[(size_t)(k) * m + j]
+#define BAT(k) B[(size_t)(k) * m + j]
   // LU factorisation of T - lam I with partial pivoting (row k against row k+1)
   double p = d[0] - lam, q = n > 1 ? e[0] : 0.0, r = 0.0;
-  for (int k0 = 0; k0 < n - 1; k0 += 8) {
-    double e8[9], d8[8];   // e[k0 .. k0 + 8], d[k0 + 1 .. k0 + 8], requested together
+  for (int k0 = 0; k0 < n - 1; k0 += kSteinFac) {
+    double ec[kSteinFac + 1], dc[kSteinFac];   // e[k0 .. k0 + C], d[k0 + 1 .. k0 + C], requested together
 #pragma unroll
-    for (int u = 0; u < 9; ++u) e8[u] = e[min(k0 + u, n - 2)];
+    for (int u = 0; u < kSteinFac + 1; ++u) ec[u] = e[min(k0 + u, n - 2)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d8[u] = d[min(k0 + 1 + u, n - 1)];
+    for (int u = 0; u < kSteinFac; ++u) dc[u] = d[min(k0 + 1 + u, n - 1)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kSteinFac; ++u) {
       const int k = k0 + u;
       if (k < n - 1) {
-        const double sub = e8[u];
-        const double dn = d8[u] - lam;
-        const double en = (k + 2 < n) ? e8[u + 1] : 0.0;
+        const double sub = ec[u];
+        const double dn = dc[u] - lam;
+        const double en = (k + 2 < n) ? ec[u + 1] : 0.0;
         if (fabs(sub) > fabs(p)) {          // swap: pivot row is (sub, dn, en)
           const double mult = p / sub;
-          AT(u0, k) = sub; AT(u1, k) = dn; AT(u2, k) = en; AT(lm, k) = mult; AT(pv, k) = 1.0;
+          const double inv = 1.0 / sub;
+          FAT(k) = d2v{mult, 1.0};
+          BAT(k) = d4v{inv, dn * inv, en * inv, 0.0};
           p = q - mult * dn;
           q = r - mult * en;
           r = 0.0;
         } else {
           if (fabs(p) < tiny) p = copysign(tiny, p == 0.0 ? 1.0 : p);
-          const double mult = sub / p;
-          AT(u0, k) = p; AT(u1, k) = q; AT(u2, k) = r; AT(lm, k) = mult; AT(pv, k) = 0.0;
+          const double inv = 1.0 / p;
+          const double mult = sub * inv;
+          FAT(k) = d2v{mult, 0.0};
+          BAT(k) = d4v{inv, q * inv, r * inv, 0.0};
           p = dn - mult * q;
           q = en - mult * r;
           r = 0.0;
@@ -177,53 +266,50 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
     }
   }
   if (fabs(p) < tiny) p = copysign(tiny, p == 0.0 ? 1.0 : p);
-  AT(u0, n - 1) = p; AT(u1, n - 1) = 0.0; AT(u2, n - 1) = 0.0;
+  BAT(n - 1) = d4v{1.0 / p, 0.0, 0.0, 0.0};
 
   for (int i = 0; i < n; ++i) X[i] = hash_unit((unsigned)j + 1u, (unsigned)i + 1u);
   for (int iter = 0; iter < 4; ++iter) {
-    // forward: apply the row interchanges and multipliers.  The running entry stays in a register, the factors and
-    // the next entries of x come in chunks of 8 rows requested together (the loop is a dependent chain: without that it
-    // waits for memory in every row)
+    // forward: apply the row interchanges and multipliers.  The running entry stays in a register
     {
       double xk = X[0];
-      for (int k0 = 0; k0 < n - 1; k0 += 8) {
-        double xn8[8], pv8[8], lm8[8];
+      for (int k0 = 0; k0 < n - 1; k0 += kSteinFw) {
+        double xn[kSteinFw];
+        d2v f[kSteinFw];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kSteinFw; ++u) {
           const int k = min(k0 + u, n - 2);
-          xn8[u] = X[k + 1];
-          pv8[u] = AT(pv, k);
-          lm8[u] = AT(lm, k);
+          xn[u] = X[k + 1];
+          f[u] = FAT(k);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kSteinFw; ++u) {
           if (k0 + u < n - 1) {
-            double xn = xn8[u];
-            if (pv8[u] != 0.0) { const double t = xk; xk = xn; xn = t; }
-            xn -= lm8[u] * xk;
+            double xv = xn[u];
+            if (f[u][1] != 0.0) { const double t = xk; xk = xv; xv = t; }
+            xv -= f[u][0] * xk;
             X[k0 + u] = xk;
-            xk = xn;
+            xk = xv;
           }
         }
       }
       X[n - 1] = xk;
     }
-    // back substitution with the three diagonals of U, same chunking
+    // back substitution with the three (scaled) diagonals of U
     double x1 = 0.0, x2 = 0.0, nrm = 0.0;
-    for (int k0 = n - 1; k0 >= 0; k0 -= 8) {
-      double xr[8], a0[8], a1[8], a2[8];
+    for (int k0 = n - 1; k0 >= 0; k0 -= kSteinBw) {
+      double xr[kSteinBw];
+      d4v bb[kSteinBw];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSteinBw; ++u) {
         const int k = max(k0 - u, 0);
         xr[u] = X[k];
-        a0[u] = AT(u0, k);
-        a1[u] = AT(u1, k);
-        a2[u] = AT(u2, k);
+        bb[u] = BAT(k);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kSteinBw; ++u) {
         if (k0 - u >= 0) {
-          const double xv = (xr[u] - a1[u] * x1 - a2[u] * x2) / a0[u];
+          const double xv = xr[u] * bb[u][0] - bb[u][1] * x1 - bb[u][2] * x2;
           X[k0 - u] = xv;
           x2 = x1;
           x1 = xv;
@@ -232,15 +318,36 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
       }
     }
     // rescale (max-norm) to stay in range; final 2-normalisation is done by the QR step
+    // (the rows in chunks of 32 requested together: a plain loop waits for memory in every row)
     const double s = nrm > 0.0 ? 1.0 / nrm : 1.0;
     double ss = 0.0;
-    for (int k = 0; k < n; ++k) { const double xv = X[k] * s; X[k] = xv; ss += xv * xv; }
+    for (int k0 = 0; k0 < n; k0 += 32) {
+      double xc[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) xc[u] = X[min(k0 + u, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        if (k0 + u < n) {
+          const double xv = xc[u] * s;
+          X[k0 + u] = xv;
+          ss += xv * xv;
+        }
+      }
+    }
     if (iter == 3) {
       const double inv = 1.0 / sqrt(ss);
-      for (int k = 0; k < n; ++k) X[k] *= inv;
+      for (int k0 = 0; k0 < n; k0 += 32) {
+        double xc[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) xc[u] = X[min(k0 + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          if (k0 + u < n) X[k0 + u] = xc[u] * inv;
+      }
     }
   }
-#undef AT
+#undef FAT
+#undef BAT
 }
 
 // G (m x m, sum of `splits` slices, summed in place into slice 0) -> upper Cholesky factor R (G = R^T R, in
@@ -284,8 +391,9 @@ __global__ __launch_bounds__(256) void k_chol_inv(double* __restrict__ g_all, lo
 }  // namespace
 
 size_t stein_workspace_doubles(int n, int m) {
-  // factors 5 n m + second X buffer n m + Gram slices 32 m^2 + Rinv m^2 (+ alignment)
-  return (size_t)6 * n * m + (size_t)33 * m * m + 64;
+  // factors 6 n m (16-byte forward + 32-byte backward records) + second X buffer n m + Gram slices 32 m^2 + Rinv m^2
+  // (+ alignment)
+  return (size_t)7 * n * m + (size_t)33 * m * m + 64;
 }
 
 // Eigenvalues il..iu (0-based, inclusive) into d_w (batch, m) and eigenvectors of T into d_x (batch, n, m
@@ -318,8 +426,8 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   for (int round = 0; round < 2; ++round) {
     for (int b = 0; b < batch; ++b) {
       double* ws = d_ws + (size_t)b * stride_ws;
-      double* x2 = ws + (size_t)5 * n * m;
-      double* gram = ws + (size_t)6 * n * m;
+      double* x2 = ws + (size_t)6 * n * m;
+      double* gram = ws + (size_t)7 * n * m;
       double* rinv = gram + (size_t)32 * m * m;
       const double* xin = (round == 0 ? d_x + (size_t)b * stride_x : x2);
       double* xout = (round == 0 ? x2 : d_x + (size_t)b * stride_x);
@@ -339,7 +447,7 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
     SC_TRY(launch_gemm_f64(ctx, d_descs, batch, m, m, kGemmTile, splits, false, false, kGemmAkBk));
     {
-      double* gram0 = d_ws + (size_t)6 * n * m;
+      double* gram0 = d_ws + (size_t)7 * n * m;
       hipLaunchKernelGGL(k_chol_inv, dim3((unsigned)batch), dim3(256), 0, st, gram0, stride_ws, m, splits,
                          gram0 + (size_t)32 * m * m, stride_ws);
     }
