@@ -3631,11 +3631,17 @@ __global__ __launch_bounds__(256) void k_bt2_wave(const double* __restrict__ sb_
 // workgroups and a fraction of the critical path.  Config C5 (one 24000 x 24000 matrix): 596 -> 307 ms.
 int symm_split_for(int n, int batch) {
   static const int env = [] { const char* e = getenv("SPRINGCRAFT_SYMM_SPLIT"); return e ? atoi(e) : 0; }();
-  if (env >= 1) return std::min(env, 8);
+  if (env >= 1) return std::min(env, 16);
   const long long tiles = (long long)batch * ((n + 63) / 64);
   if (tiles >= 1024 || n < 2048) return 1;
   // (one 24000 x 24000 matrix: 3 slices 338 ms, 6 slices 307 ms, 8 slices 378 ms of SYMM time)
-  return (int)std::min<long long>(6, (2048 + tiles - 1) / tiles);
+  // Round 5, same matrix, `tools/r05_symm_sweep.sh`: 4 slices 407 ms, 5: 312, 6: 325, 7: 299, 8: 395, 9: 285, 10: 295,
+  // 12: 303 -- slice counts that share a factor with the 8 XCDs put the same slice of every tile on the same XCD (the
+  // workgroups are dealt round-robin) and with it the long K ranges of the triangle: ODD counts spread them.  Nine where six
+  // were taken (at most 409 tiles: one large matrix or a few); the smaller counts of larger launches are unchanged
+  // (n = 6000, one to four matrices: 6, 7 and 9 slices within 1 %).
+  const long long s0 = std::min<long long>(6, (2048 + tiles - 1) / tiles);
+  return s0 >= 6 ? 9 : (int)s0;
 }
 
 size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
