@@ -57,9 +57,12 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
   // the 16 counts an eigenvalue needs.  The product form p_i = a_i p_{i-1} - b_i p_{i-2} (a_i = (d_i - x) s,
   // b_i = (e_{i-1} s)^2, q_i = p_i / p_{i-1}) has ONE fused multiply-add in the chain (b_i p_{i-2} is known a step
   // earlier); the eigenvalues below x are the sign changes of the sequence, as Wilkinson's bisection counted them.  The
-  // rows are scaled by s = 1 / (Gershgorin radius) so that |a_i| <= 2, b_i <= 1: a sequence grows by at most 3^8 between
-  // two re-normalisations (every 8 rows, by the exponent of the larger of the last two members).  An exact zero takes
-  // the sign opposite to its predecessor -- dstebz's q = -pivmin.
+  // rows are scaled by s = 1 / (Gershgorin radius) so that |a_i| <= 2, b_i <= 1: a sequence grows by at most 3^4 between
+  // two re-normalisations (every 4 rows, by the exponent of the larger of the last two members).  An exact zero takes
+  // the sign opposite to its predecessor -- dstebz's q = -pivmin.  What the product form gives up against the ratio form:
+  // rows whose entries AND distance to the shift are below ~1e-60 of the matrix' norm shrink the sequence into underflow
+  // and then count as decoupled zeros -- shifts that small are 44 orders below the eps |T| to which a tridiagonal matrix
+  // that came out of an orthogonal reduction is known at all (tools/models/sturm_product_model.py, tests/test_sturm_model.py).
   // The rows reach the chain through LDS: lane l of the wave loads row 64 c + l of a 64-row chunk c (two coalesced loads
   // per chunk and lane instead of 2 x 64 loads of one address each), a group of four chunks ahead of the one in work; a
   // chunk in work is written to LDS once (16 bytes per lane) and every step reads its row as ONE broadcast ds_read_b128.
@@ -129,8 +132,10 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) STURM_STEP(r8[q])
-            STURM_RENORM()
+            for (int q = 0; q < 8; ++q) {
+              STURM_STEP(r8[q])
+              if ((q & 3) == 3) STURM_RENORM()
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) r8[q] = n8[q];
           }
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
           for (int u = 0; u < lim; ++u) {
             const d2s r = rows[t & 1][u];
             STURM_STEP(r)
-            if ((u & 7) == 7) STURM_RENORM()
+            if ((u & 3) == 3) STURM_RENORM()
           }
           STURM_RENORM()
         }
