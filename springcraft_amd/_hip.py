@@ -8,6 +8,7 @@ shared library is missing, or no gfx950 device is visible, every compute entry p
 
 import ctypes as C
 import os
+import threading
 import warnings
 from os.path import abspath, dirname, exists, join
 
@@ -398,7 +399,7 @@ _PIN_POOL_MAX = 1 << 30
 _pin_free = {}          # bytes -> [address, ...]
 _pin_live = 0
 _pin_idle = 0
-_pin_lock = None
+_pin_lock = threading.Lock()
 
 
 def _pin_release(address, nbytes):
@@ -417,8 +418,7 @@ def _pin_release(address, nbytes):
 
 def host_array(shape):
     """A C-contiguous float64 array for a result that comes back from the device (see above)."""
-    global _pin_lock, _pin_live, _pin_idle
-    import threading
+    global _pin_live, _pin_idle
     import weakref
 
     shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
@@ -426,8 +426,6 @@ def host_array(shape):
     nbytes = 8 * count
     if nbytes < _PIN_MIN or os.environ.get("SPRINGCRAFT_PINNED_RESULTS", "1") == "0":
         return np.empty(shape)
-    if _pin_lock is None:
-        _pin_lock = threading.Lock()
     address = None
     with _pin_lock:
         if _pin_live + nbytes > _PIN_LIVE_MAX:
