@@ -504,11 +504,14 @@ def test_result_arrays_on_pooled_page_locked_memory(sc):
     import gc
     import os
 
-    from springcraft_amd import nma
+    from springcraft_amd import _hip, nma
 
     n = 1201                                   # (a size no other test leaves blocks of in the pool)
     a = sym(np.random.RandomState(5), n)
+    live0 = _hip._pin_live
     w, v = nma.eigh(a)
+    # (page-locking may be refused by the box -- the arrays then live on ordinary memory and only the results are checked)
+    pooled = os.environ.get("SPRINGCRAFT_PINNED_RESULTS", "1") != "0" and _hip._pin_live - live0 >= 8 * n * n
     assert isinstance(v, np.ndarray) and v.flags.writeable and v.flags.c_contiguous
     w_ref = np.linalg.eigvalsh(a)
     assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
@@ -521,7 +524,6 @@ def test_result_arrays_on_pooled_page_locked_memory(sc):
     gc.collect()
     w3, v3 = nma.eigh(a)                       # both blocks are back in the pool: one of them is reused
     assert np.array_equal(v3[5], keep)
-    pooled = os.environ.get("SPRINGCRAFT_PINNED_RESULTS", "1") != "0"
     if pooled:
         assert v3.ctypes.data in (first, second)
     view = v3[:10]
