@@ -3640,8 +3640,10 @@ int symm_split_for(int n, int batch) {
   // workgroups are dealt round-robin) and with it the long K ranges of the triangle: ODD counts spread them.  Nine where six
   // were taken (at most 409 tiles: one large matrix or a few); the smaller counts of larger launches are unchanged
   // (n = 6000, one to four matrices: 6, 7 and 9 slices within 1 %).
+  // The middle regime follows the same rule (`tools/r05_symm_mid.sh`, 6 x n = 6000 = 564 tiles: 4 slices 38.9 ms of SYMM
+  // per step, 5 slices 31.0): an even count takes the next odd one.
   const long long s0 = std::min<long long>(6, (2048 + tiles - 1) / tiles);
-  return s0 >= 6 ? 9 : (int)s0;
+  return s0 >= 6 ? 9 : (int)(s0 | 1);
 }
 
 size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
