@@ -73,9 +73,12 @@ int sc_dbg_bt2_trace(unsigned long long* out);
  * with k > 0], until the diagonal block D is in LDS, until the end; tasks; tasks with k > 0}.  tools/bulge_stamps.py */
 int sc_dbg_bulge_stamps(unsigned long long* out6);
 /* The same for the pair form of the persistent chase (k_bulge_pair; library built with -DPAIR_STAMPS, else returns 1):
- * out16[0..7] = cycles of thread 0 between the nine barriers of a step (wait, loads, E right update + reflector,
- * column sums, E left update + D products, w, D update, store drain), [8] = steps, [9] = steps with both teams at work. */
-int sc_dbg_pair_stamps(unsigned long long* out16);
+ * 48 entries.  [0..15] thread 0 (team A): [0..6] = cycles between the barriers of a common step (wait + [0], block reads +
+ * [1], E right update + reflector, column sums + D image, E left update + D products, w, D update), [8] = steps, [9] =
+ * common steps, [12] = block reads alone; [16..31] thread 256 (team B), same layout, [26] slot reads, [27] store drain,
+ * [29] D update + stores; [32..47] lane 0 of the first loader wave (k_bulge_pair<1>): [32] wait for E, [33] barrier [0],
+ * [34] [1] [2], [35] wait for D, [36] [3] [4], [37] E requests, [38] [5] [6] [7], [39] D requests, [40] steps counted. */
+int sc_dbg_pair_stamps(unsigned long long* out48);
 /* The same for the persistent chase with one sweep per workgroup (k_bulge_chase; library built with -DCHASE_STAMPS, else
  * returns 1): out16[1..11] = cycles of all waves between eleven points of a task, summed over all tasks since the last call
  * (the segments are listed at the macro in twostage.hip), [15] = waves x tasks.  tools/chase_stamps.py */
@@ -95,6 +98,10 @@ int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after);
  * (SPRINGCRAFT_QR_COOP / SPRINGCRAFT_QR_COOP_MIN).  Counters "panel_coop_launches" / "panel_coop_timeouts".
  * tests/test_two_stage_gpu.py */
 int sc_dbg_set_panel_coop(sc_ctx* ctx, int min_rows);
+/* Test hook of the cooperative panel kernel's take-over: from panel `panel` on (-1: never) the abort flags of all
+ * matrices are raised before the launch, as after a wait that ran into its bound; k_panel_serial then factors that panel
+ * and every later one, counted in "panel_coop_timeouts". */
+int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel);
 
 #ifdef __cplusplus
 }

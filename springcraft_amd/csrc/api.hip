@@ -85,8 +85,34 @@ int sc_stage_end(sc_ctx* ctx) {
   return SC_OK;
 }
 
+int sc_collect_events(sc_ctx* ctx) {
+  if (!ctx->d_status) return SC_OK;
+  unsigned long long h[kSpStatusWords] = {0};
+  SC_HIP(ctx, hipMemcpy(h, ctx->d_status, sizeof(h), hipMemcpyDeviceToHost));
+  bool any = false;
+  for (int i = 2; i < kSpStatusWords; ++i) any = any || h[i] != 0;
+  if (any) SC_HIP(ctx, hipMemset(ctx->d_status + 2, 0, sizeof(unsigned long long) * (kSpStatusWords - 2)));
+  ctx->cnt_chase_resumed += (long long)h[2];
+  ctx->cnt_chase_timeouts += (long long)h[3];
+  ctx->cnt_chase_sweeps += (long long)h[4];
+  ctx->cnt_coop_timeouts += (long long)h[5];
+  ctx->cnt_chase_incomplete += (long long)h[6];
+  // a context whose persistent kernels ran into a bound keeps to the launch-per-wavefront / chunked forms from here on
+  if (h[3] || h[6]) ctx->chase_ok = 0;
+  if (h[5]) ctx->coop_ok = 0;
+  if (ctx->last_chase_ctl) {   // the most recent chase's control block: tickets per XCD, where a wait timed out
+    int c[32] = {0};
+    SC_HIP(ctx, hipMemcpy(c, ctx->last_chase_ctl, sizeof(c), hipMemcpyDeviceToHost));
+    for (int x = 0; x < 8; ++x) ctx->chase_tickets[x] = c[2 + x];
+    if (c[0] && c[1] == 0) { ctx->chase_wait[0] = c[10]; ctx->chase_wait[1] = c[11]; ctx->chase_wait[2] = c[12]; }
+    ctx->last_chase_ctl = nullptr;
+  }
+  return SC_OK;
+}
+
 int sc_deferred_status(sc_ctx* ctx) {
   if (!ctx->d_status) return SC_OK;
+  SC_TRY(sc_collect_events(ctx));
   unsigned long long h[2] = {0, 0};
   SC_HIP(ctx, hipMemcpy(h, ctx->d_status, sizeof(h), hipMemcpyDeviceToHost));
   if (h[0] == 0 && h[1] == 0) return SC_OK;
@@ -114,6 +140,7 @@ int sc_reserve_dc_aux(sc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->dc_aux_bytes) return SC_OK;
   if (ctx->dc_aux) {
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_TRY(sc_collect_events(ctx));   // (the last chase's control block lives in the buffer that goes away)
     SC_HIP(ctx, hipFree(ctx->dc_aux));
     ctx->dc_aux = nullptr;
     ctx->dc_aux_bytes = 0;
@@ -170,8 +197,8 @@ int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
   } else {
     ctx->stream = (hipStream_t)stream;
   }
-  if (hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_status, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc((void**)&ctx->d_status, kSpStatusWords * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_status, 0, kSpStatusWords * sizeof(unsigned long long)) != hipSuccess) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SC_ERR_NOMEM;
@@ -407,6 +434,11 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms) {
 int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   if (!ctx || !name || !value) return SC_ERR_INVALID_ARG;
   const std::string k(name);
+  // (round 6: what the persistent kernels report is collected on the device while solves are enqueued; a diagnostic call
+  // may wait for the stream)
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SC_TRY(sc_collect_events(ctx));
   int tmin = ctx->chase_tickets[0], tmax = ctx->chase_tickets[0];
   for (int x = 1; x < 8; ++x) {
     tmin = std::min(tmin, ctx->chase_tickets[x]);
@@ -442,6 +474,13 @@ int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after) {
   ctx->chase_mode = mode;
   ctx->chase_give_up = give_up_after;
   if (mode >= 0) ctx->chase_ok = -1;
+  return SC_OK;
+}
+
+int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel) {
+  if (!ctx || panel < -1) return SC_ERR_INVALID_ARG;
+  ctx->coop_fail_panel = panel;
+  if (panel >= 0) ctx->coop_ok = -1;
   return SC_OK;
 }
 

@@ -6,6 +6,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -51,6 +53,11 @@ struct sc_ctx {
   int h_stage_cur = 0;
   // deferred status of the device-pointer eigensolver entries (which do not synchronise): [0] = 1 + index of a matrix
   // with a NaN / Inf entry, [1] = the tridiagonal QL iteration failed.  Read and cleared by sc_deferred_status.
+  // Round 6, events a solve no longer looks at from the host (kSpStatusWords words; sc_collect_events adds them to the
+  // counters below at the next synchronising call): [2] persistent chases that k_chase_finish had to finish, [3] of
+  // those: after a time-out (not the test hook), [4] sweeps the persistent kernels finished, [5] panels factored by
+  // k_panel_serial after k_panel_coop gave up, [6] chases left incomplete without a raised flag (an XCD that owns
+  // matrices received no workgroup).
   unsigned long long* d_status = nullptr;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
@@ -74,6 +81,8 @@ struct sc_ctx {
   // once a wait between its workgroups timed out (the context then keeps to the chunked panel launches)
   int coop_attr = -1, coop_ok = -1;
   int coop_min_rows = -1;   // debug entry sc_dbg_set_panel_coop: rows from which a panel takes it (0 never, -1 default rule)
+  int coop_fail_panel = -1; // debug entry sc_dbg_set_panel_coop_fail: panel from which the abort flags are raised (test hook)
+  int* last_chase_ctl = nullptr;   // control block of the most recent persistent chase (in dc_aux), read by sc_collect_events
   long long cnt_coop_launches = 0, cnt_coop_timeouts = 0;
   // event counters since the context was created (sc_ctx_get_counter)
   long long cnt_chase_launches = 0, cnt_chase_timeouts = 0, cnt_chase_incomplete = 0, cnt_chase_resumed = 0,
@@ -165,7 +174,10 @@ int sc_stage_upload(sc_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int sc_stage_end(sc_ctx* ctx);
 // after a synchronisation of ctx->stream: SC_ERR_NOCONV (and the flags cleared) if a solve since the last call met
 // non-finite input or a QL failure, else SC_OK
+constexpr int kSpStatusWords = 16;
 int sc_deferred_status(sc_ctx* ctx);
+// adds the device-side event words to the context's counters (the context's stream must be idle)
+int sc_collect_events(sc_ctx* ctx);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -245,3 +257,21 @@ int modes_dcc_device(sc_ctx* ctx, const double* d_v, const double* d_w, int64_t 
                      int64_t nsel, int norm, char* scratch, double* d_out);
 int modes_prs_device(sc_ctx* ctx, const double* d_v, const double* d_w, int64_t n, double rcond, int norm,
                      char* scratch, double* d_out);
+
+// Raises a kernel's dynamic LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (device, kernel).  The
+// attribute belongs to the device that is current when it is set: a function-local static done-flag (rounds 2-5) served
+// the first device a process used and left contexts on a second GPU with refused launches.  Returns
+// whether the limit is in place on the CURRENT device; the caller has made its context's device current.
+inline bool sc_raise_dyn_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, bool> done;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> g(mu);
+  const auto key = std::make_pair(dev, fn);
+  const auto it = done.find(key);
+  if (it != done.end()) return it->second;
+  const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  done[key] = ok;
+  return ok;
+}

@@ -385,12 +385,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
 template <int BM, int BN, bool AM, bool BNC, bool TRI, bool GATHER = false>
 void launch_gemm2_inst(hipStream_t st, dim3 grid, const GemmDesc* d_desc, int split_k, bool lower = false) {
   constexpr size_t lds = sizeof(double) * 2 * (size_t)(StageImage<BM, AM>::kSize + StageImage<BN, BNC>::kSize);
-  static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI, GATHER>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return true;
-  }();
-  (void)attr_set;
+  // (per device: sc_raise_dyn_lds; a refusal surfaces as the launch error the caller checks)
+  (void)sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_gemm2<BM, BN, AM, BNC, TRI, GATHER>), (int)lds);
   if (lower) {   // square launch: only the tiles of the lower triangle
     static_assert(BM % BN == 0, "row tiles are whole multiples of column tiles");
     const unsigned tiles = (unsigned)((long long)(BM / BN) * grid.x * (grid.x + 1) / 2);

@@ -880,6 +880,10 @@ __global__ __launch_bounds__(kCoopRows) void k_panel_coop(double* __restrict__ a
   double* A = a_all + (size_t)mat * stride_a;
   double* tri = tri_all + (size_t)mat * TL.slab;
   double* sb = sb_all + (size_t)mat * SL.slab;
+  // (round 6: one control record of 8 ints per matrix -- [0] the abort flag its workgroups poll, [1..5] what was waited
+  // for --, so that a matrix whose wait timed out does not stop the matrices beside it half-way through their stores)
+  ctl += 8 * (int)blockIdx.y;
+  if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // given up in an earlier panel: k_panel_serial
   v4i* colrec = recs_all + (size_t)mat * coop_recs_per_matrix(G);
   v4i* mrec = colrec + (size_t)2 * G * 16;
   v4i* trec = mrec + (size_t)G * kCoopVals;
@@ -1078,6 +1082,90 @@ __global__ __launch_bounds__(kCoopRows) void k_panel_coop(double* __restrict__ a
   }
 }
 
+// The take-over of k_panel_coop, enqueued behind every one of its launches (round 6; until then a time-out failed the
+// solve).  Workgroup b looks at matrix b's control record and returns unless its abort flag is up -- always, in practice.
+// Otherwise the panel is intact in memory (k_panel_coop stores nothing before its last exchange has succeeded) and is
+// factored here by this ONE workgroup, from memory, column by column: norm and pivot, reflector, the columns on the right
+// eight at a time (w = tau (v^T P), P -= v w) -- slow (the panel is streamed 64 / 8 + 1 times per column group) and only
+// there so that a solve whose cooperative launch could not get its workgroups resident together (another stream or
+// process holds CUs with a persistent kernel of its own) still ends with LAPACK's numbers.  The flag stays up for the
+// rest of the solve; the event is counted in stats[5] and the context keeps to the chunked launches afterwards.
+__global__ __launch_bounds__(1024) void k_panel_serial(double* __restrict__ a_all, long long stride_a,
+                                                       double* __restrict__ tri_all, TriLayout TL,
+                                                       double* __restrict__ sb_all, SbLayout SL, int j0,
+                                                       const int* __restrict__ ctl, unsigned long long* __restrict__ stats) {
+  __shared__ double red[16 * 9];
+  __shared__ double s_w[8];
+  __shared__ double s_tau, s_beta, s_scale;
+  const int mat = blockIdx.x;
+  if (ctl[8 * mat] == 0) return;
+  const int n = TL.n;
+  const int r0 = j0 + kB, m = n - r0;
+  double* A = a_all + (size_t)mat * stride_a;
+  double* tri = tri_all + (size_t)mat * TL.slab;
+  double* sb = sb_all + (size_t)mat * SL.slab;
+  double* P = A + (size_t)j0 * n + r0;      // P(r, c) at P[c * n + r], r = 0 .. m - 1, c = 0 .. kB - 1
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) atomicAdd(stats + 5, 1ull);
+  // sum of up to 8 values per thread over the workgroup: wave sums, then 16 partials per value
+  auto block_sum8 = [&](double (&a)[8], int cnt) {
+    for (int i = 0; i < cnt; ++i) {
+      const double t = wave_sum(a[i]);
+      if (lane == 0) red[wv * 9 + i] = t;
+    }
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      double t = 0.0;
+      for (int w = 0; w < 16; ++w) t += red[w * 9 + i];
+      a[i] = t;
+    }
+    __syncthreads();
+  };
+  for (int j = 0; j < kB; ++j) {
+    double* pj = P + (size_t)j * n;
+    {
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = j + 1 + tid; r < m; r += 1024) a[0] += pj[r] * pj[r];
+      block_sum8(a, 1);
+      if (tid == 0) {
+        const HH h = householder(pj[j], a[0]);
+        s_tau = h.tau; s_beta = h.beta; s_scale = h.scale;
+        tri[TL.tau + j0 + j] = h.tau;
+      }
+      __syncthreads();
+    }
+    const double tau = s_tau, scale = s_scale;
+    for (int c0 = j + 1; c0 < kB; c0 += 8) {
+      const int cnt = min(8, kB - c0);
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = j + 1 + tid; r < m; r += 1024) {
+        const double x = pj[r];
+        for (int i = 0; i < cnt; ++i) a[i] += x * P[(size_t)(c0 + i) * n + r];
+      }
+      block_sum8(a, cnt);
+      if (tid < cnt) s_w[tid] = tau * (P[(size_t)(c0 + tid) * n + j] + scale * a[tid]);
+      __syncthreads();
+      for (int r = j + tid; r < m; r += 1024) {
+        const double v = r > j ? scale * pj[r] : 1.0;
+        for (int i = 0; i < cnt; ++i) P[(size_t)(c0 + i) * n + r] -= v * s_w[i];
+      }
+      __syncthreads();
+    }
+    // column j in the form the matrix takes it: R above the pivot (untouched), beta at it, v below
+    for (int r = j + tid; r < m; r += 1024) pj[r] = r > j ? scale * pj[r] : s_beta;
+    __syncthreads();
+  }
+  // V in its explicit form into the three panel buffers (as k_panel_coop's last loop)
+  for (int c = 0; c < kB; ++c)
+    for (int r = tid; r < m; r += 1024) {
+      const double val = P[(size_t)c * n + r];
+      const double v = r > c ? val : (r == c ? 1.0 : 0.0);
+      sb[SL.vw + (size_t)c * n + r0 + r] = v;
+      sb[SL.wv + (size_t)(kB + c) * n + r0 + r] = -v;
+      sb[SL.xv + (size_t)(2 * kB + c) * n + r0 + r] = v;
+    }
+}
+
 // X1 / X2 = sum of their K slices (split-K SYMM, few matrices): blockIdx.y = column of [X1 | X2], rows r0 .. n - 1
 __global__ __launch_bounds__(256) void k_sum_xslices(double* __restrict__ sb_all, SbLayout SL, int r0) {
   const int n = SL.n, p = SL.symm_split;
@@ -1252,22 +1340,25 @@ __device__ __forceinline__ gdptr wave_uniform(double* p) {
   return (gdptr)(size_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 
-// Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
-__global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
-                                                    int t, const int* __restrict__ done = nullptr) {
+// One task (sweep s, chase position k) of the bulge chase by one workgroup of 256 threads, blocks from and to the band
+// storage: the body of k_bulge_step (one launch per wavefront of tasks) and of k_chase_finish (the take-over after a
+// persistent chase that gave up).
+struct BulgeTaskLds {
+  double E[kB * (kB + 1)];
+  double vp[kB], vn[kB], u[kB], red[4 * kB];
+  double s_tau, s_beta;
+};
+__device__ __forceinline__ void bulge_task(double* __restrict__ sb, const SbLayout& SL, int s, int k, BulgeTaskLds& W) {
   constexpr int LD = kB + 1;
-  __shared__ double E[kB * LD];
-  double* D = E;   // the diagonal block is processed after E has gone back to memory: same buffer
-  __shared__ double vp[kB], vn[kB], u[kB], red[4 * kB];
-  __shared__ double s_tau, s_beta;
-
+  double* const E = W.E;
+  double* const D = E;   // the diagonal block is processed after E has gone back to memory: same buffer
+  double* const vp = W.vp;
+  double* const vn = W.vn;
+  double* const u = W.u;
+  double* const red = W.red;
+  double& s_tau = W.s_tau;
+  double& s_beta = W.s_beta;
   const int n = SL.n;
-  const int k = (t & 1) + 2 * (int)blockIdx.x;
-  const int s = (t - k) / 2;
-  if (s < 0 || s > n - 3 || k >= chase_len(n, s)) return;
-  // resuming a persistent chase that gave up (k_bulge_chase): done[b][s] tasks of sweep s are finished already
-  if (done && k < done[(size_t)blockIdx.y * n + s]) return;
-  double* sb = sb_all + (size_t)blockIdx.y * SL.slab;
   double* ab = sb + SL.ab;
   const int S = s / kG, cc = s - S * kG;
   // diamonds of group S start at sum_{S' < S} chase_len(n, 64 S') = S K0 - S (S - 1) / 2  (K0 = chase_len(n, 0))
@@ -1420,6 +1511,57 @@ __global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_a
     }
   }
 #endif
+}
+
+// Launch t of the bulge chase: workgroup x handles task (s, k) with k = (t & 1) + 2x, s = (t - k) / 2.
+__global__ __launch_bounds__(256, 4) void k_bulge_step(double* __restrict__ sb_all, SbLayout SL,
+                                                    int t, const int* __restrict__ done = nullptr) {
+  __shared__ BulgeTaskLds W;
+  const int n = SL.n;
+  const int k = (t & 1) + 2 * (int)blockIdx.x;
+  const int s = (t - k) / 2;
+  if (s < 0 || s > n - 3 || k >= chase_len(n, s)) return;
+  // resuming a persistent chase that gave up (k_bulge_chase): done[b][s] tasks of sweep s are finished already
+  if (done && k < done[(size_t)blockIdx.y * n + s]) return;
+  bulge_task(sb_all + (size_t)blockIdx.y * SL.slab, SL, s, k, W);
+}
+
+// Take-over after a persistent chase (k_bulge_chase / k_bulge_pair), enqueued behind every one of them so that the host
+// never has to look at the chase's outcome inside a solve (round 6: the solve only enqueues).  A chase that completed
+// -- always, in practice -- costs this launch a look at the control block.  Otherwise (the stop flag is up: a wait ran
+// into its bound or the test hook fired; or an XCD that owns matrices received no workgroup) workgroup b finishes matrix
+// b alone, task after task in the order sweep, position from the published counts -- a valid order of the chase's
+// dependences whatever the state the workgroups left behind, and slow: it is the last line of defence, counted in
+// stats[] (read at the next synchronising call: sc_collect_events), after which the context keeps to the per-wavefront
+// launches.  stats (unsigned long long, sc_ctx::d_status): [2] chases that needed it, [3] of those: stop flag raised by a
+// time-out (not by the test hook), [4] sweeps finished by the persistent kernels (all chases), [6] incomplete without a flag.
+__global__ __launch_bounds__(256) void k_chase_finish(double* __restrict__ sb_all, SbLayout SL, int batch, int nxcd,
+                                                      int* __restrict__ progress, const int* __restrict__ ctl,
+                                                      unsigned long long* __restrict__ stats) {
+  __shared__ BulgeTaskLds W;
+  const int n = SL.n;
+  const int b = blockIdx.x;
+  long long sweeps = 0;
+  for (int x = 0; x < 8; ++x) sweeps += ctl[16 + x];
+  const bool complete = ctl[0] == 0 && sweeps == (long long)batch * (n - 2);
+  if (b == 0 && threadIdx.x == 0) {
+    atomicAdd(stats + 4, (unsigned long long)sweeps);
+    if (!complete) {
+      atomicAdd(stats + 2, 1ull);
+      if (ctl[0] && ctl[1] == 0) atomicAdd(stats + 3, 1ull);
+      if (!ctl[0]) atomicAdd(stats + 6, 1ull);
+    }
+  }
+  if (complete) return;
+  int* prog = progress + (size_t)b * n;
+  double* sb = sb_all + (size_t)b * SL.slab;
+  for (int s = 0; s <= n - 3; ++s) {
+    const int len = chase_len(n, s);
+    for (int k = prog[s]; k < len; ++k) {
+      bulge_task(sb, SL, s, k, W);
+      __syncthreads();   // (the task's stores are visible to this workgroup's next task: same CU, same L1 / L2 path)
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1826,22 +1968,38 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
 // workgroup writes its live slots back to the band and publishes both sweeps' counts, so the per-wavefront launches can
 // finish the chase from the counters exactly as after k_bulge_chase.
 constexpr int kSlotE = kB * (kB + 1);          // E block, row stride 65 (conflict-free column access)
-constexpr int kSlotD = kB * (kB + 1) / 2;      // D block, lower triangle packed by rows: (i, j) at i (i + 1) / 2 + j
+// D block, lower triangle packed by rows: (i, j) at i (i + 1) / 2 + j (2080 doubles).  The region is a little larger: the
+// loader waves (below) land the triangle packed by COLUMNS in 16-byte pieces, column j as ceil((64 - j) / 2) pieces from
+// piece pair_cc(j) on: 1056 pieces, fetched by 17 LDS-DMA instructions of 64 pieces = 2176 doubles.
+constexpr int kSlotD = 17 * 128;
 constexpr int kSlot = kSlotE + kSlotD;
+// first 16-byte piece of column jj of the landed triangle: sum over j' < jj of ceil((64 - j') / 2)
+__host__ __device__ constexpr int pair_cc(int jj) { return 32 * jj - (jj >> 1) * ((jj - 1) >> 1); }
+static_assert(pair_cc(0) == 0 && pair_cc(1) == 32 && pair_cc(2) == 64 && pair_cc(3) == 95 && pair_cc(64) == 1056, "pieces");
 constexpr int kTeamLds = 2 * kB + kB + 4 * kB + 8;   // vbuf[2][64], u[64], red[256], tau, beta (+ pad)
 constexpr size_t kPairLdsBytes = sizeof(double) * (3 * kSlot + 2 * kTeamLds);
 
 // Diagnostic build (-DPAIR_STAMPS): shader cycles of thread 0 between the barriers of every step, summed over all steps
 // of all workgroups since the last read (sc_dbg_pair_stamps, tools/pair_stamps.py); nothing of it in the normal build.
+// (round 6: the sums are kept in LDS -- one writer per entry: thread 0 [0..15], thread 256 [16..31], lane 0 of the first
+// loader wave [32..47] -- and added to the global table when the thread leaves the kernel: a global atomic per stamp
+// more than doubled the stage's time)
 #ifdef PAIR_STAMPS
-__device__ unsigned long long g_pair_stamps[16];
+__device__ unsigned long long g_pair_stamps[48];
+__shared__ unsigned long long s_pair_stamps[48];
 #define PAIR_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
-#define PAIR_ACC(slot, a, b) if (tid == 0) atomicAdd(&g_pair_stamps[slot], (b) - (a));
-#define PAIR_ACC_B(slot, a, b) if (tid == 256) atomicAdd(&g_pair_stamps[slot], (b) - (a));
+#define PAIR_ACC(slot, a, b) if (tid == 0) s_pair_stamps[slot] += (b) - (a);
+#define PAIR_ACC_B(slot, a, b) if (tid == 256) s_pair_stamps[16 + (slot)] += (b) - (a);
+#define PAIR_ACC_L(slot, a, b) if (lw == 0 && lane == 0) s_pair_stamps[32 + (slot)] += (b) - (a);
+#define PAIR_FLUSH(first)                                                                         \
+  for (int i_ = 0; i_ < 16; ++i_)                                                                 \
+    if (s_pair_stamps[(first) + i_]) atomicAdd(&g_pair_stamps[(first) + i_], s_pair_stamps[(first) + i_]);
 #else
 #define PAIR_STAMP(var)
 #define PAIR_ACC(slot, a, b)
 #define PAIR_ACC_B(slot, a, b)
+#define PAIR_ACC_L(slot, a, b)
+#define PAIR_FLUSH(first)
 #endif
 
 // The common step of k_bulge_pair: both teams at work on full 64-row blocks, neither at a sweep start.  Same barriers
@@ -1860,11 +2018,16 @@ struct PairStepArgs {
   size_t dia;
   int cc;
   int tid;
+  const int* prev;   // the predecessor sweep's counter (null: none, or no early read) and the stop flag: read behind [1]
+  const int* ctl;
 };
 
-template <int TEAM>
-__device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& tau_p, int& pend_k) {
-  const int tid = P.tid, tt = tid & 255, i = tid & 63, q = (tid >> 6) & 3;
+// LOADER = 1: team A's blocks have been landed in its slot by the loader waves (k_bulge_pair's header): E column by column
+// ((i, j) at j * 64 + i), the triangle of D by columns in 16-byte pieces (pair_cc) -- A issues no global load.
+template <int TEAM, int LOADER>
+__device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& tau_p, int& pend_k, int& h_have, int& h_stop) {
+  const int tid = P.tid, tt = tid & 255, i = tid & 63;
+  const int q = LOADER ? __builtin_amdgcn_readfirstlane((tid >> 6) & 3) : (tid >> 6) & 3;
   const int k = P.k, s = P.s;
   const int r0 = s + 1 + k * kB;
   ldptr vp = P.vbuf + ((k + 1) & 1) * kB;
@@ -1880,8 +2043,14 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
   double d16[16], t16[16], vr[16];
   PAIR_STAMP(f0)
   if (TEAM == 0) {
+    if (LOADER) {
+      const ldptr ecol = Eimg + q * 16 * kB + i;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) t16[c] = ld_l2(ebase_k + (o_e + (unsigned)(c * (kLdab - 1))));
+      for (int c = 0; c < 16; ++c) t16[c] = ecol[c * kB];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t16[c] = ld_l2(ebase_k + (o_e + (unsigned)(c * (kLdab - 1))));
+    }
   } else {
     const ldptr En = P.slots + ((k + 1) % 3) * kSlot;
     const int i1 = min(i + 1, kB - 1);
@@ -1910,7 +2079,13 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
   if (TEAM == 1) {
     if (tt == 0 && pend_k >= 0) __hip_atomic_store(P.prog + s, pend_k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_k = k;
-  } else {
+    // the NEXT step's look at the predecessor pair, requested a step ahead (k_bulge_pair: "early look"): this wave has no
+    // load in flight and its stores of this step come later, so the values are there when the step ends
+    if (tt == 0 && P.prev) {
+      h_have = __hip_atomic_load(P.prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      h_stop = __hip_atomic_load(P.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (!LOADER) {
     // D is not touched before step (5): its loads are issued here, behind the barrier, so that the other team does not
     // wait for their issue (under load the memory pipeline takes a block's 16 load instructions per wave slowly: issuing
     // them costs as much as waiting for the data) and land behind steps (2)-(4).  Entries above the diagonal: whatever
@@ -1951,6 +2126,13 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
 #pragma unroll
     for (int c = 0; c < 16; ++c) a += ecol[c * (kB + 1)] * vr[c];
     red[q * kB + i] = a;
+  }
+  if (TEAM == 0 && LOADER) {
+    // the landed triangle (complete since barrier [3]) into the registers, row i: entry (i, jj) is entry i - jj of
+    // column jj; above the diagonal whatever lies in front of the column (masked below).  All of it is read before
+    // barrier [4], behind which the row-packed image takes the region over.
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d16[c] = Dimg[2 * pair_cc(q * 16 + c) - (q * 16 + c) + i];
   }
   lds_barrier();                                                                  // [4]
   if (tt < kB) u[tt] = P.sc[0] * ((red[tt] + red[kB + tt]) + (red[2 * kB + tt] + red[3 * kB + tt]));
@@ -2018,6 +2200,7 @@ __device__ __forceinline__ void pair_step_full(const PairStepArgs& P, double& ta
   {
     PAIR_STAMP(f8)
     PAIR_ACC(1, f0, f1) PAIR_ACC(2, f1, f3) PAIR_ACC(3, f3, f5) PAIR_ACC(4, f5, f6) PAIR_ACC(5, f6, f7) PAIR_ACC(6, f7, f8)
+    PAIR_ACC_B(1, f0, f1) PAIR_ACC_B(2, f1, f3) PAIR_ACC_B(3, f3, f5) PAIR_ACC_B(4, f5, f6) PAIR_ACC_B(5, f6, f7)
     PAIR_ACC_B(13, f7, f8)
   }
 #endif
@@ -2037,12 +2220,17 @@ struct PairGenArgs {
   int n, s, k, my_len, team, to_lds;
   size_t dia0;
   int cc, tid;
+  const int* prev;   // (as in PairStepArgs)
+  const int* ctl;
 };
 struct PairCarry {
   double tau_p;
   int pend_k;
+  int h_have, h_stop;
 };
 
+// (one copy per kernel instantiation: a shared copy would be compiled for the smaller register budget of the two)
+template <int LOADER>
 __device__ __noinline__ PairCarry pair_step_general(const PairGenArgs P, double tau_p, int pend_k) {
   double* const ab = P.ab;
   const ldptr slots = P.slots, vbuf = P.vbuf, u = P.u, red = P.red, sc = P.sc;
@@ -2122,6 +2310,11 @@ __device__ __noinline__ PairCarry pair_step_general(const PairGenArgs P, double 
     if (pend_k + 1 == my_len) atomicAdd(P.sweeps_done, 1);
   }
   pend_k = -1;
+  int h_have = 0, h_stop = 0;
+  if (team == 1 && tt == 0 && P.prev) {   // the next step's early look (see pair_step_full)
+    h_have = __hip_atomic_load(P.prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h_stop = __hip_atomic_load(P.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   
   // ---- (2) u = tau_p E vp: partial sums over this wave's 16 columns
   if (eph) {
@@ -2233,7 +2426,7 @@ __device__ __noinline__ PairCarry pair_step_general(const PairGenArgs P, double 
     tau_p = tau_now;
     if (!to_lds) pend_k = k;   // published once the stores have drained: behind the next step's loads
   }
-  return PairCarry{tau_p, pend_k};
+  return PairCarry{tau_p, pend_k, h_have, h_stop};
 }
 
 // (the few fields of the band workspace's layout the kernel needs, instead of all of SbLayout in scalar registers)
@@ -2242,19 +2435,200 @@ struct PairLayout {
   long long slab, ab, vd, tau2;
 };
 
-__global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_all, PairLayout SL, int batch, int W, int nxcd,
+// ---- Loader waves (round 6, LOADER = 1: 768 threads).  In the form above only team A's 256 threads issue global loads,
+// in one of the step's eight phases, and wait for them in the next: the memory system has this CU's requests in flight
+// for a fraction of the step.  Here waves 8-11 issue nothing but LDS-DMA (global_load_lds_dwordx4: 64 x 16 bytes from
+// per-lane addresses to one contiguous KB of LDS, no VGPR for the data, no VALU instruction in steady state) and fetch
+// team A's blocks of position m + 1 while the compute waves are in step m:
+//   * where to: the slot of position m + 1 is the slot of position m - 2, which team B emptied at the start of step m and
+//     uses as its scratch image -- the E image until barrier [4], the D image until barrier [6].  So E(m + 1) is requested
+//     behind [4] (32 instructions: two columns each, 8 per loader wave behind ONE write of M0) and the triangle of
+//     D(m + 1) behind [7] (17 instructions of 64 pieces, see kSlotD; the second M0 write of a wave waits for its E pieces
+//     in flight -- behind [7] nobody waits for the loader before the next [0], which needs E landed anyway);
+//   * handshake: a loader wave arrives at the next step's barrier [0] with its E pieces landed (s_waitcnt vmcnt(#D)) and
+//     at barrier [3] with everything landed.  Team A reads E from the slot in front of [1] (column-major as landed: row
+//     accesses are conflict-free), re-writes it row-major behind [2] as before; it reads its rows of D between [3] and
+//     [4] and writes the row-packed image behind [4] as before;
+//   * only the common step is served (both teams on full blocks): the loaders evaluate the same predicate for m + 1 as
+//     the compute waves, the general step loads for itself as before;
+//   * the predecessor pair must have left position m + 1 by the time it is fetched: thread 0's wait in front of step m
+//     covers m + 3 instead of m + 2 of its tasks when a fetch follows;
+//   * only the triangle of D crosses the fabric (17 KB instead of the 32 KB square whose upper half was masked).
+// The loader waves execute every workgroup barrier of the compute waves, in the same number.
+__device__ __forceinline__ bool pair_common_step(bool hasB, int m, int lenA, int sA, int n) {
+  return hasB && m >= 3 && m < lenA && sA + 1 + (m + 1) * kB <= n;
+}
+
+// The loader waves of k_bulge_pair<1> (its header): the same claims, steps and workgroup barriers as the compute waves.
+__device__ __forceinline__ void pair_loader_run(double* __restrict__ sb_all, const PairLayout& SL, int nxcd, int xcd, int slot,
+                                                int mpx, const volatile __attribute__((address_space(3))) int* s_claim,
+                                                const volatile __attribute__((address_space(3))) int* s_go,
+                                                unsigned lds_base, int lw, int lane) {
+  const int n = SL.n;
+  // per-lane byte offsets of this wave's pieces, once per kernel (nothing of it changes from step to step).
+  // E: wave lw fetches column pairs 8 lw .. 8 lw + 7; instruction x lands at M0 + (1024 x - 3584) + 16 lane; lanes 0-31
+  // take rows (2 l, 2 l + 1) of the even column, lanes 32-63 those of the odd one (its pieces start 127 doubles later).
+  // D: wave lw fetches instructions d0 .. d0 + nd - 1 of the 17 (5, 4, 4, 4), instruction x lands at M0 + (1024 x - 2048)
+  // + 16 lane; piece g = 64 (d0 + x) + lane is piece g - pair_cc(j) of column j; pieces beyond the 1056 re-read the last.
+  const int ld_d0 = lw == 0 ? 0 : 1 + 4 * lw;
+  unsigned voff_e[8], voff_d[5];
+  {
+    const unsigned lane_off = lane < 32 ? 16u * lane : (unsigned)(8 * (kLdab - 1)) + 16u * (lane - 32);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) voff_e[x] = lane_off + (unsigned)(16 * (kLdab - 1) * (8 * lw + x)) - (unsigned)(1024 * x) + 3584u;
+#pragma unroll
+    for (int x = 0; x < 5; ++x) {
+      const int g = min(64 * (ld_d0 + x) + lane, pair_cc(kB) - 1);
+      int j = 0;
+      while (pair_cc(j + 1) <= g) ++j;
+      voff_d[x] = (unsigned)(8 * (j * kLdab + 2 * (g - pair_cc(j)))) - (unsigned)(1024 * x) + 2048u;
+    }
+  }
+  int cur = slot % mpx, exhausted = 0;
+  while (exhausted < mpx) {
+    const int b = xcd + nxcd * cur;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int sA = 2 * __builtin_amdgcn_readfirstlane(*s_claim);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (sA > n - 3) {
+      ++exhausted;
+      cur = cur + 1 < mpx ? cur + 1 : 0;
+      continue;
+    }
+    exhausted = 0;
+    const unsigned long long ab_u = (unsigned long long)(size_t)wave_uniform(sb_all + (size_t)b * SL.slab + SL.ab);
+    const bool hasB = sA + 1 <= n - 3;
+    const int lenA = chase_len(n, sA);
+    const int nsteps = hasB ? lenA + 2 : lenA;
+    for (int m = 0; m < nsteps; ++m) {
+      PAIR_STAMP(l0)
+      if (pair_common_step(hasB, m, lenA, sA, n)) {
+        // this step's E pieces have landed (the D pieces requested after them may still be on their way)
+        if (lw == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      PAIR_STAMP(l1)
+      __builtin_amdgcn_s_barrier();                                                     // [0]
+      PAIR_STAMP(l2)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int go = __builtin_amdgcn_readfirstlane(*s_go);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!go) {
+        // give-up: the pieces in flight land in the slot nobody flushes; then the compute waves' barriers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (hasB) __builtin_amdgcn_s_barrier();
+        if (lw == 0 && lane == 0) { PAIR_FLUSH(32) }
+        return;
+      }
+      // ---- a step of a loader wave: the compute waves' seven barriers, position m + 1 requested behind [4] and [7]
+      const bool fetch = pair_common_step(hasB, m + 1, lenA, sA, n);
+      __builtin_amdgcn_s_barrier();                                                     // [1]
+      __builtin_amdgcn_s_barrier();                                                     // [2]
+      PAIR_STAMP(l3)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's D pieces have landed
+      PAIR_STAMP(l4)
+      __builtin_amdgcn_s_barrier();                                                     // [3]
+      __builtin_amdgcn_s_barrier();                                                     // [4]
+      PAIR_STAMP(l5)
+      const int r0n = sA + 1 + (m + 1) * kB;
+      const unsigned slot_b = lds_base + (unsigned)(((m + 1) % 3) * kSlot * 8);
+#ifdef PAIR_VAR_NODMA
+      if (false) {
+#else
+      if (fetch) {
+#endif
+        const unsigned long long eb = ab_u + ((unsigned long long)(r0n - kB) * kLdab + kB) * 8ull;   // E(0, 0) of position m + 1
+        const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot_b + (unsigned)(1024 * 8 * lw + 3584)));
+        asm volatile(
+            "s_mov_b32 m0, %0\n\ts_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %9 offset:-3584\n\t"
+            "global_load_lds_dwordx4 %2, %9 offset:-2560\n\t"
+            "global_load_lds_dwordx4 %3, %9 offset:-1536\n\t"
+            "global_load_lds_dwordx4 %4, %9 offset:-512\n\t"
+            "global_load_lds_dwordx4 %5, %9 offset:512\n\t"
+            "global_load_lds_dwordx4 %6, %9 offset:1536\n\t"
+            "global_load_lds_dwordx4 %7, %9 offset:2560\n\t"
+            "global_load_lds_dwordx4 %8, %9 offset:3584"
+            :
+            : "s"(m0v), "v"(voff_e[0]), "v"(voff_e[1]), "v"(voff_e[2]), "v"(voff_e[3]), "v"(voff_e[4]), "v"(voff_e[5]),
+              "v"(voff_e[6]), "v"(voff_e[7]), "s"(eb)
+            : "memory");
+      }
+      PAIR_STAMP(l6)
+      __builtin_amdgcn_s_barrier();                                                     // [5]
+      __builtin_amdgcn_s_barrier();                                                     // [6]
+      __builtin_amdgcn_s_barrier();                                                     // [7]
+      PAIR_STAMP(l7)
+#ifdef PAIR_VAR_NODMA
+      if (false) {
+#else
+      if (fetch) {
+#endif
+        const unsigned long long db = ab_u + (unsigned long long)r0n * kLdab * 8ull;                  // D(0, 0) of position m + 1
+        const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot_b + (unsigned)(kSlotE * 8 + 1024 * ld_d0 + 2048)));
+        if (lw == 0)
+          asm volatile(
+              "s_mov_b32 m0, %0\n\ts_nop 4\n\t"
+              "global_load_lds_dwordx4 %1, %6 offset:-2048\n\t"
+              "global_load_lds_dwordx4 %2, %6 offset:-1024\n\t"
+              "global_load_lds_dwordx4 %3, %6\n\t"
+              "global_load_lds_dwordx4 %4, %6 offset:1024\n\t"
+              "global_load_lds_dwordx4 %5, %6 offset:2048"
+              :
+              : "s"(m0v), "v"(voff_d[0]), "v"(voff_d[1]), "v"(voff_d[2]), "v"(voff_d[3]), "v"(voff_d[4]), "s"(db)
+              : "memory");
+        else
+          asm volatile(
+              "s_mov_b32 m0, %0\n\ts_nop 4\n\t"
+              "global_load_lds_dwordx4 %1, %5 offset:-2048\n\t"
+              "global_load_lds_dwordx4 %2, %5 offset:-1024\n\t"
+              "global_load_lds_dwordx4 %3, %5\n\t"
+              "global_load_lds_dwordx4 %4, %5 offset:1024"
+              :
+              : "s"(m0v), "v"(voff_d[0]), "v"(voff_d[1]), "v"(voff_d[2]), "v"(voff_d[3]), "s"(db)
+              : "memory");
+      }
+#ifdef PAIR_STAMPS
+      if (fetch && pair_common_step(hasB, m, lenA, sA, n)) {
+        PAIR_STAMP(l8)
+        PAIR_ACC_L(0, l0, l1) PAIR_ACC_L(1, l1, l2) PAIR_ACC_L(2, l2, l3) PAIR_ACC_L(3, l3, l4) PAIR_ACC_L(4, l4, l5)
+        PAIR_ACC_L(5, l5, l6) PAIR_ACC_L(6, l6, l7) PAIR_ACC_L(7, l7, l8) PAIR_ACC_L(8, 0ull, 1ull)
+      }
+#endif
+    }
+    // ---- end of the pair (nothing is in flight: the last steps fetch nothing)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (lw == 0 && lane == 0) { PAIR_FLUSH(32) }
+}
+
+// (diagnostic variants, tools/r06_pair_variants.sh: PAIR_VAR_CAP168 compiles the 512-thread form for the register budget
+// of the 768-thread one; PAIR_VAR_NODMA keeps the loader waves and their barriers but requests nothing -- wrong results)
+#ifdef PAIR_VAR_CAP168
+#define PAIR_BOUNDS(LOADER) 768
+#else
+#define PAIR_BOUNDS(LOADER) (LOADER ? 768 : 512)
+#endif
+template <int LOADER>
+__global__ __launch_bounds__(PAIR_BOUNDS(LOADER), 1) void k_bulge_pair(double* __restrict__ sb_all, PairLayout SL, int batch, int W, int nxcd,
                                                       int* __restrict__ progress, int* __restrict__ next_pair,
-                                                      int* __restrict__ ctl, int give_up_after) {
-  extern __shared__ double pair_lds[];
+                                                      int* __restrict__ ctl, int give_up_after, int early_look) {
+  extern __shared__ __attribute__((aligned(16))) double pair_lds[];
   __shared__ int s_go, s_claim, s_xcd, s_slot;
 
   const int n = SL.n;
   const int tid = threadIdx.x;
   // (the team is uniform over a wave: told to the compiler, so that the position, the step's case and the branches on
   // them are scalar)
-  const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >= 8 ? 0 : wave >> 2;
   const int tt = tid & 255;
   double* const slots = pair_lds;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)pair_lds;
   double* const tl = pair_lds + 3 * kSlot + team * kTeamLds;
   double* const vbuf = tl;
   double* const u = tl + 2 * kB;
@@ -2267,10 +2641,18 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
     s_xcd = (int)(id & 7u) % nxcd;
     s_slot = atomicAdd(ctl + 2 + s_xcd, 1);
   }
+#ifdef PAIR_STAMPS
+  if (tid < 48) s_pair_stamps[tid] = 0;
+#endif
   __syncthreads();
   const int xcd = s_xcd, slot = s_slot;
   const int mpx = xcd < batch ? (batch - xcd + nxcd - 1) / nxcd : 0;   // matrices of this XCD: xcd, xcd + nxcd, ...
   if (mpx == 0 || slot >= mpx * W) return;
+  if (LOADER && wave >= 8) {
+    pair_loader_run(sb_all, SL, nxcd, xcd, slot, mpx, (const volatile __attribute__((address_space(3))) int*)&s_claim,
+                    (const volatile __attribute__((address_space(3))) int*)&s_go, lds_base, wave - 8, tid & 63);
+    return;
+  }
   const int K0 = chase_len(n, 0);
   int steps_left = give_up_after;
 
@@ -2301,21 +2683,39 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
     double tau_p = 0.0;
 
     const int nsteps = hasB ? lenA + 2 : lenA;
-    int have_c = 0;      // thread 0: last value seen of the predecessor's counter (it only grows)
+    // ---- the look at the predecessor pair (A's dependence; B's are inside the workgroup), by thread 256: the first wave of
+    // team B opens a step with LDS reads only.  Round 6, "early look": followers run at the dependence's limit -- pair p + 1
+    // starts when its workgroup has finished pair p - 3, a few steps behind pair p, and both advance at the same rate -- so a
+    // look taken when the step begins was needed in 0.6 of all steps and cost 2 300 cycles of a 16 900-cycle step, all
+    // other waves waiting at [0] (profiles/r06_pair_stamps.txt).  Now the counter and the stop flag are requested behind
+    // barrier [1] of the PREVIOUS step and are in a register when this step begins; a value that does not cover the step
+    // falls back to polling, for one task more than needed, which buys the step of distance that keeps the early values
+    // sufficient from there on.
+    int have_c = 0;      // thread 256: last value seen of the predecessor's counter (it only grows)
+    int h_have = 0, h_stop = 0;
+    const int* prev = (early_look && sA > 0) ? prog + sA - 1 : nullptr;
     int pend_k = -1;     // task of this team whose stores are on their way: published behind the next step's loads
     for (int m = 0; m < nsteps; ++m) {
-      // ---- wait for the predecessor pair (A's dependence; B's are inside the workgroup).  The counter is read again only
-      // when the cached value does not cover this step; the stop flag with it, and every eighth step
       PAIR_STAMP(ts0)
-      if (tid == 0) {
-        const int need = (sA > 0 && m < lenA) ? min(m + 2, len_prev) : 0;
+      if (tid == 256) {
+        // (a step whose successor is fetched ahead by the loader waves needs the predecessor one task further)
+        const int ahead = LOADER && pair_common_step(hasB, m + 1, lenA, sA, n) ? 3 : 2;
+        const int need = (sA > 0 && m < lenA) ? min(m + ahead, len_prev) : 0;
         int go = 1;
-        if (have_c < need || (m & 7) == 0) {
+        if (prev) {
+          have_c = max(have_c, h_have);
+          if (h_stop) go = 0;
+        }
+        if (go && (have_c < need || (!prev && (m & 7) == 0))) {
+#ifdef PAIR_STAMPS
+          s_pair_stamps[16 + 10] += 1ull;
+#endif
+          const int want = prev ? min(need + 1, len_prev) : need;
           const int stop0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           int have = sA > 0 ? __hip_atomic_load(prog + sA - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
           if (stop0) go = 0;
           long spins = 0;
-          while (go && have < need) {
+          while (go && have < want) {
             // (2^21 polls of ~1 us: seconds, orders of magnitude above any wait for a running workgroup)
             ++spins;
             if (spins > (1L << 21) ||
@@ -2334,6 +2734,7 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
         }
         s_go = go;
       }
+      PAIR_STAMP(tsp)
       lds_barrier();   // [0] (also: A's last slot writes of the previous step are ordered before B's reads below)
       if (!s_go) {
         // ---- give up between steps.  First the pending publish (its stores drained), then: A has finished positions
@@ -2367,31 +2768,36 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
             __hip_atomic_store(prog + sA + 1, min(max(m - 2, 0), lenB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        if (tid == 0) { PAIR_FLUSH(0) }
+        if (tid == 256) { PAIR_FLUSH(16) }
         return;
       }
 
       PAIR_STAMP(ts1)
       const int k = team ? m - 2 : m;
       // ---- the common step: both teams at work on full 64-row blocks, neither at a sweep start (pair_step_full)
-      if (hasB && m >= 3 && m < lenA && sA + 1 + (m + 1) * kB <= n) {
+      if (pair_common_step(hasB, m, lenA, sA, n)) {
         PairStepArgs pa{ab, sb + SL.vd, sb + SL.tau2, (ldptr)slots, (ldptr)vbuf, (ldptr)u, (ldptr)red, (ldptr)sc, prog, s, k,
-                        dia0 + k, cc, tid};
-        if (team == 0) pair_step_full<0>(pa, tau_p, pend_k);
-        else pair_step_full<1>(pa, tau_p, pend_k);
+                        dia0 + k, cc, tid, prev, ctl};
+        if (team == 0) pair_step_full<0, LOADER>(pa, tau_p, pend_k, h_have, h_stop);
+        else pair_step_full<1, LOADER>(pa, tau_p, pend_k, h_have, h_stop);
 #ifdef PAIR_STAMPS
-        if (tid == 0) { atomicAdd(&g_pair_stamps[9], 1ull); atomicAdd(&g_pair_stamps[0], ts1 - ts0); }
+        if (tid == 0) { s_pair_stamps[9] += 1ull; s_pair_stamps[0] += ts1 - ts0; }
+        if (tid == 256) { s_pair_stamps[16] += ts1 - ts0; s_pair_stamps[16 + 7] += tsp - ts0; }
 #endif
       } else {
         PairGenArgs ga{ab, sb + SL.vd, sb + SL.tau2, (ldptr)slots, (ldptr)vbuf, (ldptr)u, (ldptr)red, (ldptr)sc, prog,
-                       ctl + 16 + xcd, n, s, k, my_len, team, to_lds ? 1 : 0, dia0, cc, tid};
-        const PairCarry pc = pair_step_general(ga, tau_p, pend_k);
+                       ctl + 16 + xcd, n, s, k, my_len, team, to_lds ? 1 : 0, dia0, cc, tid, prev, ctl};
+        const PairCarry pc = pair_step_general<LOADER>(ga, tau_p, pend_k);
         tau_p = pc.tau_p;
         pend_k = pc.pend_k;
+        h_have = pc.h_have;
+        h_stop = pc.h_stop;
       }
       // (no barrier here: the next step's [0] orders this step's slot writes before their readers, and nothing else of
       // the next step touches LDS before it)
 #ifdef PAIR_STAMPS
-      if (tid == 0) atomicAdd(&g_pair_stamps[8], 1ull);
+      if (tid == 0) s_pair_stamps[8] += 1ull;
 #endif
       if (tid == 0) {
         if (to_lds && m + 1 == lenA) atomicAdd(ctl + 16 + xcd, 1);   // (A's last task; its count is published below)
@@ -2412,6 +2818,8 @@ __global__ __launch_bounds__(512, 1) void k_bulge_pair(double* __restrict__ sb_a
     }
     if (tid == 0 && hasB) __hip_atomic_store(prog + sA, lenA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) { PAIR_FLUSH(0) }
+  if (tid == 256) { PAIR_FLUSH(16) }
 }
 
 // ================================================================================================================
@@ -3841,7 +4249,6 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const int coop_gmax = (std::max(n - kB, 1) + kCoopRows - 1) / kCoopRows;
   v4i* coop_recs = nullptr;
   int* coop_ctl = nullptr;
-  bool coop_used = false;
   // (only when the whole batch runs on one stream: the parts of a split batch must not be factored by different kernels --
   // other reduction trees, other last bits -- or the same structure at two batch positions gives different eigenvalues)
   static const int env_s1_early = [] { const char* e = getenv("SPRINGCRAFT_STAGE1_STREAMS"); return e ? atoi(e) : 0; }();
@@ -3854,11 +4261,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const int nb_max = std::min(batch, coop_budget / coop_gmax);
     if (ctx->coop_attr == 1 && nb_max >= 1) {
       const size_t rec_bytes = (size_t)batch * coop_recs_per_matrix(coop_gmax) * sizeof(v4i);
-      SC_TRY(sc_reserve_dc_aux(ctx, 256 + rec_bytes));
+      const size_t ctl_bytes = align_up((size_t)batch * 8 * sizeof(int), 256);   // one control record per matrix
+      SC_TRY(sc_reserve_dc_aux(ctx, ctl_bytes + rec_bytes));
       coop_ctl = reinterpret_cast<int*>(ctx->dc_aux);
-      coop_recs = reinterpret_cast<v4i*>(reinterpret_cast<char*>(ctx->dc_aux) + 256);
+      coop_recs = reinterpret_cast<v4i*>(reinterpret_cast<char*>(ctx->dc_aux) + ctl_bytes);
       // (sequence numbers are unique within a solve only)
-      SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, 256 + rec_bytes, st));
+      SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, ctl_bytes + rec_bytes, st));
     }
   }
   // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, the trailing update
@@ -3894,10 +4302,14 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const bool use_coop = coop_recs != nullptr && nr == kB && m >= (nb < 4 ? coop_min_few : coop_min_many) &&
                           nb * coop_g <= coop_budget && ps == st;
     if (use_coop) {
+      // (test hook, sc_dbg_set_panel_coop_fail: from this panel on the matrices' abort flags are up, as after a time-out)
+      if (p == ctx->coop_fail_panel) SC_HIP(ctx, hipMemsetAsync(coop_ctl + 8 * lo, 1, sizeof(int) * 8 * nb, ps));
       hipLaunchKernelGGL(k_panel_coop, dim3((unsigned)coop_g, (unsigned)nb), dim3(kCoopRows), kCoopLdsBytes, ps, a_h, stride_a,
-                         tri_h, TL, sb_h, SQ, j0, coop_g, coop_recs + (size_t)lo * coop_recs_per_matrix(coop_g), coop_ctl,
-                         (p + 1) * 128);
-      coop_used = true;
+                         tri_h, TL, sb_h, SQ, j0, coop_g, coop_recs + (size_t)lo * coop_recs_per_matrix(coop_g),
+                         coop_ctl + 8 * lo, (p + 1) * 128);
+      // the take-over: returns at once unless a wait of the launch above (or of an earlier panel) timed out
+      hipLaunchKernelGGL(k_panel_serial, dim3((unsigned)nb), dim3(1024), 0, ps, a_h, stride_a, tri_h, TL, sb_h, SQ, j0,
+                         (const int*)(coop_ctl + 8 * lo), ctx->d_status);
       ++ctx->cnt_coop_launches;
     } else if (use_wg) {
       const size_t lds_wg = sizeof(double) * (size_t)(2 * kWgWaves * 8 + 16 + 8 + 8 * kB + kWgWaves * kB * 8);
@@ -3992,21 +4404,6 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     for (int p = 0; p < npanels; ++p) SC_TRY(run_panel(p, 0, batch, st, true));
   }
   SC_HIP(ctx, hipGetLastError());
-  if (coop_used) {
-    // a wait of k_panel_coop that ran into its bound (never expected: its workgroups were not resident together for
-    // seconds): the factorisation is not to be trusted -- an error, and this context keeps to the chunked launches
-    int h_flag[8] = {0};
-    SC_HIP(ctx, hipMemcpyAsync(h_flag, coop_ctl, sizeof(h_flag), hipMemcpyDeviceToHost, st));
-    SC_HIP(ctx, hipStreamSynchronize(st));
-    if (h_flag[0]) {
-      ctx->coop_ok = 0;
-      ++ctx->cnt_coop_timeouts;
-      ctx->err = "cooperative panel QR: a wait between its workgroups timed out (kind " + std::to_string(h_flag[1]) +
-                 ", tag wanted " + std::to_string(h_flag[2]) + ", seen " + std::to_string(h_flag[3]) + ", at " +
-                 std::to_string(h_flag[4]) + ", workgroup " + std::to_string(h_flag[5]) + ")";
-      return SC_ERR_NOCONV;
-    }
-  }
   if (prof) SC_HIP(ctx, hipEventRecord(ev[1], st));
 
   // ---- stage 2
@@ -4038,8 +4435,15 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // matrix chases 1.6 x faster with its ~188 tasks per wavefront spread over the whole chip (411 vs 676 ms)
     static const bool use_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return !e || atoi(e) != 0; }();
     static const int force_pair = [] { const char* e = getenv("SPRINGCRAFT_BULGE_PAIR"); return e ? atoi(e) : -1; }();
+    // SPRINGCRAFT_PAIR_LOADER = 1: the pair form with its loader waves (k_bulge_pair<1>, 768 threads: measured, slower --
+    // profiles/r06_pair_stamps.txt; default: the 512-thread form)
+    static const bool pair_loader = [] { const char* e = getenv("SPRINGCRAFT_PAIR_LOADER"); return e && atoi(e) != 0; }();
+    // SPRINGCRAFT_PAIR_EARLY = 0: the pair form looks at its predecessor when a step begins (round 4) instead of a step ahead
+    static const int pair_early = [] { const char* e = getenv("SPRINGCRAFT_PAIR_EARLY"); return (!e || atoi(e) != 0) ? 1 : 0; }();
     if (ctx->pair_attr < 0)   // per device, hence per context: the caller made ctx->device current
-      ctx->pair_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair),
+      ctx->pair_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes) == hipSuccess;
     const bool pair_attr = ctx->pair_attr == 1;
     const long long work = (long long)batch * n / 128;
@@ -4067,7 +4471,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
       int per_cu = 0;
       if (pair) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_pair, 512, kPairLdsBytes) != hipSuccess) per_cu = 0;
+        const hipError_t oe = pair_loader ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_pair<1>, 768, kPairLdsBytes)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_pair<0>, 512, kPairLdsBytes);
+        if (oe != hipSuccess) per_cu = 0;
       } else {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
       }
@@ -4097,10 +4503,14 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
         // its share; the kernel does not rely on it (a short-changed XCD is just slower, see the kernel's header)
         const int grid = nxcd * std::min(slots_per_xcd, mpx * W);
         t_bulge.start();
-        if (pair)
-          hipLaunchKernelGGL(k_bulge_pair, dim3((unsigned)grid), dim3(512), kPairLdsBytes, st, d_sb_ws,
+        if (pair && pair_loader)
+          hipLaunchKernelGGL(k_bulge_pair<1>, dim3((unsigned)grid), dim3(768), kPairLdsBytes, st, d_sb_ws,
                              PairLayout{SL.n, SL.slab, SL.ab, SL.vd, SL.tau2}, batch, W, nxcd, d_prog, d_next, d_ctl,
-                             ctx->chase_give_up);
+                             ctx->chase_give_up, pair_early);
+        else if (pair)
+          hipLaunchKernelGGL(k_bulge_pair<0>, dim3((unsigned)grid), dim3(512), kPairLdsBytes, st, d_sb_ws,
+                             PairLayout{SL.n, SL.slab, SL.ab, SL.vd, SL.tau2}, batch, W, nxcd, d_prog, d_next, d_ctl,
+                             ctx->chase_give_up, pair_early);
         else
           hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
                              d_next, d_ctl, ctx->chase_give_up, d_early);
@@ -4113,42 +4523,15 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
           ++ctx->cnt_pair_fallbacks;
         }
         if (le == hipSuccess) {
-          int h_ctl[kChaseCtlInts] = {0};
-          SC_HIP(ctx, hipMemcpyAsync(h_ctl, d_ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
-          SC_HIP(ctx, hipStreamSynchronize(st));
-          long long sweeps = 0;
-          for (int x = 0; x < 8; ++x) {
-            sweeps += h_ctl[16 + x];
-            ctx->chase_tickets[x] = h_ctl[2 + x];
-          }
+          // (round 6: no look at the outcome from the host -- the take-over is a launch of its own that returns at once
+          // when the chase completed, and the control block's counts reach the context's counters at the next
+          // synchronising call: sc_collect_events)
+          hipLaunchKernelGGL(k_chase_finish, dim3((unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, batch, nxcd, d_prog,
+                             (const int*)d_ctl, ctx->d_status);
+          SC_HIP(ctx, hipGetLastError());
           ++ctx->cnt_chase_launches;
           if (pair) ++ctx->cnt_pair_launches;
-          ctx->cnt_chase_sweeps += sweeps;
-          const bool complete = sweeps == (long long)batch * (n - 2);
-          if (h_ctl[0] || !complete) {
-            // Never expected (see the kernel's header).  A raised flag means a wait ran into its bound (or the test hook
-            // fired); an incomplete chase without a flag means an XCD that owns matrices received no workgroup.  Either
-            // way workgroups only stop between tasks and every finished task is published, so the counters describe a
-            // consistent state: the per-wavefront launches finish the chase, skipping what is done.
-            if (h_ctl[0] && h_ctl[1] == 0) {
-              ++ctx->cnt_chase_timeouts;
-              ctx->chase_ok = 0;
-              ctx->chase_wait[0] = h_ctl[10]; ctx->chase_wait[1] = h_ctl[11]; ctx->chase_wait[2] = h_ctl[12];
-            } else if (!h_ctl[0]) {
-              ++ctx->cnt_chase_incomplete;
-              // an XCD that owns matrices drew no ticket: this device does not deal workgroups the way the kernel assumes
-              //  -- do not pay for a launch + take-over on every further solve of this context
-              for (int x = 0; x < nxcd && x < batch; ++x)
-                if (h_ctl[2 + x] == 0) ctx->chase_ok = 0;
-            }
-            ++ctx->cnt_chase_resumed;
-            t_bulge.start();
-            for (int t = 0; t <= t_max; ++t)
-              hipLaunchKernelGGL(k_bulge_step, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, st, d_sb_ws, SL, t,
-                                 (const int*)d_prog);
-            t_bulge.stop();
-            SC_HIP(ctx, hipGetLastError());
-          }
+          ctx->last_chase_ctl = d_ctl;
           chased = true;
         }
       }
@@ -4246,10 +4629,8 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     // the role-split form (k_bt2_role: 64 columns per workgroup, MFMA / fragment / window-row waves): SPRINGCRAFT_BT2_ROLE = 1
     static const int env_role = [] { const char* e = getenv("SPRINGCRAFT_BT2_ROLE"); return e ? atoi(e) : 0; }();
     if (env_role != 0 && (n & 1) == 0 && batch >= 8 && n >= 256) {
-      static const bool role_attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_role), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kRoleLds) == hipSuccess;
-      }();
+      // (per device, with the answer checked: sc_raise_dyn_lds)
+      const bool role_attr = sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_bt2_role), kRoleLds);
       if (role_attr) {
         const int nchunk64 = (ncols + 63) / 64;
         hipLaunchKernelGGL(k_bt2_role, dim3((unsigned)(8 * ((batch + 7) / 8) * nchunk64)), dim3(768), kRoleLds, st, d_sb_ws, SL,
@@ -4266,14 +4647,11 @@ int bt2_batched(sc_ctx* ctx, int n, int batch, double* d_sb_ws, const SbLayout& 
     // 128 columns per workgroup (8 waves) when that still gives every CU a workgroup, else 64 (4 waves)
     // ring of three half-diamond fragment buffers + one 16 x 18 transposition tile per wave
     constexpr size_t lds = sizeof(double) * (3 * kHalfDoubles + 8 * 16 * 18);
-    static const bool attr_set = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bt2_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      return true;
-    }();
-    (void)attr_set;
+    // (per device, with the answer checked -- ADVICE round 5: a process-wide flag left a context on a second GPU with a
+    // refused 138 KB launch)
+    if (!sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_bt2_apply<8>), (int)lds) ||
+        !sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_bt2_apply<4>), (int)lds))
+      return sc_set_error(ctx, SC_ERR_HIP, "k_bt2_apply: the device refuses %zu bytes of dynamic LDS", lds);
     static const int force_nw = [] { const char* e = getenv("SPRINGCRAFT_BT2_NW"); return e ? atoi(e) : 0; }();
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     int nw = ((long long)((ncols + 127) / 128) * batch >= cus) ? 8 : 4;
@@ -4343,9 +4721,9 @@ extern "C" int sc_dbg_bt2_stamps(unsigned long long* out) {
 // tasks with k > 0}, cycles since the task's start; reset after the read
 extern "C" int sc_dbg_pair_stamps(unsigned long long* out16) {
 #ifdef PAIR_STAMPS
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pair_stamps), 128) != hipSuccess) return 5;
-  const unsigned long long z[16] = {0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, 128) == hipSuccess ? 0 : 5;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pair_stamps), 384) != hipSuccess) return 5;   // (48 entries)
+  const unsigned long long z[48] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), z, 384) == hipSuccess ? 0 : 5;
 #else
   (void)out16;
   return 1;

@@ -59,3 +59,15 @@ def test_give_up_and_take_over_at_every_step():
             part, done = m.pair_chase(ab, n, abort=(sA, step), refl=refl)
             fin = m.finish_with(part, n, done, refl)
             assert np.abs(fin[:2] - ref[:2]).max() < 1e-11 and np.abs(fin[2:m.KB + 1]).max() < 1e-11, (sA, step)
+
+
+def test_loader_wave_protocol_early_and_late_delivery():
+    # round 6: team A's blocks of the common steps arrive by (emulated) LDS-DMA into the slot team B has just emptied; the
+    # kernel's offset formulas, the landing layouts and the phases of every slot access -- delivered at once or at the
+    # last moment the handshake allows
+    m = _model()
+    for n in (321, 450):
+        ab = _band(m, n, n)
+        ref = m.reference_chase(ab, n)
+        for late in (False, True):
+            assert np.array_equal(ref, m.pair_chase_loader(ab, n, late)), (n, late)

@@ -374,3 +374,106 @@ def test_pair_chase_by_size_rule(sc):
         assert np.abs(wb - w_ref).max() <= 1e-11 * np.abs(w_ref).max(), b
         assert np.abs(h @ vb.T - vb.T * wb[None, :]).max() <= 1e-10 * np.abs(w_ref).max(), b
 
+
+
+@pytest.mark.parametrize("n,batch,min_rows,fail_panel", [(1030, 3, 200, 2), (2101, 2, 128, 0), (4700, 1, -1, 5)])
+def test_cooperative_panel_take_over(n, batch, min_rows, fail_panel):
+    """
+    Round 6: a wait of k_panel_coop that runs into its bound no longer fails the
+    solve.  The test hook raises the matrices' abort flags in front of panel `fail_panel`: the cooperative launches from
+    there on return at once (nothing stored), the take-over k_panel_serial behind each of them factors the panel from
+    memory, the solve ends with LAPACK's eigenvalues and orthonormal vectors, the event is counted, and the context then
+    keeps to the chunked launches (no cooperative launch in the second solve).
+    """
+    import ctypes as C
+    import os
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    if os.environ.get("SPRINGCRAFT_QR_COOP") == "0" or os.environ.get("SPRINGCRAFT_QR_COOP_MIN") or \
+            (batch > 1 and int(os.environ.get("SPRINGCRAFT_STAGE1_STREAMS") or 0) > 1):
+        pytest.skip("the cooperative kernel's rule is overridden (tools/test_matrix.sh)")
+    L = _hip.lib()
+    for f in (L.sc_dbg_set_panel_coop, L.sc_dbg_set_panel_coop_fail):
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int]
+    rs = np.random.RandomState(23 + n + batch)
+    mats = np.stack([sym(rs, n) for _ in range(batch)])
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_two_stage(True)
+        ctx.check(L.sc_dbg_set_panel_coop(ctx.handle, min_rows))
+        ctx.check(L.sc_dbg_set_panel_coop_fail(ctx.handle, fail_panel))
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        for attempt in range(2):
+            a = torch.from_numpy(mats.copy()).cuda()
+            torch.cuda.synchronize()
+            before = ctx.counter("panel_coop_launches")
+            ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                        C.c_void_p(v.data_ptr())))
+            ctx.synchronize()              # no error: the solve was finished on the device
+            launches = ctx.counter("panel_coop_launches") - before
+            if attempt == 0:
+                lo = (300 if batch < 4 else 6145) if min_rows < 0 else min_rows
+                coop_panels = sum(1 for p in range(n // 64 + 1) if n - (p + 1) * 64 >= max(lo, 65))
+                assert launches == coop_panels and coop_panels > fail_panel
+                # every panel from the hooked one on, of every matrix
+                assert ctx.counter("panel_coop_timeouts") == batch * (coop_panels - fail_panel)
+            else:
+                assert launches == 0       # the context keeps to the chunked launches after the event
+            am = torch.from_numpy(mats).cuda()
+            eye = torch.eye(n, dtype=torch.float64, device="cuda")
+            for b in range(batch):
+                r = am[b] @ v[b].T - v[b].T * w[b][None, :]
+                assert float(r.abs().max()) <= 1e-10 * float(w[b].abs().max()), (attempt, b)
+                assert float((v[b] @ v[b].T - eye).abs().max()) <= 1e-11, (attempt, b)
+                w_ref = np.linalg.eigvalsh(mats[b])
+                assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+            ctx.check(L.sc_dbg_set_panel_coop_fail(ctx.handle, -1)) if attempt == 1 else None
+    finally:
+        ctx.close()
+
+
+def test_device_solve_only_enqueues_at_n6000():
+    """
+    Round 6: a device-pointer solve has no stream synchronisation inside -- the outcome of the
+    persistent chase and of the cooperative panel kernel is dealt with by take-over launches on the device and read at
+    the next synchronising call.  One n = 6000 matrix (cooperative panels + persistent chase, the path that used to
+    synchronise twice): the call returns while most of the solve is still ahead.
+    """
+    import ctypes as C
+    import time
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    n = 6000
+    rs = np.random.RandomState(3)
+    m0 = sym(rs, n)
+    L = _hip.lib()
+    ctx = _hip.Context(0)
+    try:
+        w = torch.empty((1, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((1, n, n), dtype=torch.float64, device="cuda")
+        t_call, t_total = [], []
+        for it in range(3):                # (the first solve allocates the workspace and raises LDS limits)
+            a = torch.from_numpy(m0.copy()).cuda()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, 1, C.c_void_p(w.data_ptr()),
+                                        C.c_void_p(v.data_ptr())))
+            t1 = time.perf_counter()
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            t_call.append(t1 - t0)
+            t_total.append(t2 - t0)
+        assert ctx.counter("chase_launches") == 3 and ctx.counter("chase_resumed") == 0
+        assert min(t_call[1:]) < 0.3 * min(t_total[1:]), (t_call, t_total)
+        w_ref = np.linalg.eigvalsh(m0)
+        assert np.abs(w[0].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.close()

@@ -20,7 +20,7 @@ solver = DeviceBatchSolver(n_atoms, B, sc.HinsenForceField())
 solver.ctx.set_two_stage(True)
 L = _hip.lib()
 L.sc_dbg_set_chase(solver.ctx.handle, 3, 0)           # persistent chase always, pair form
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 48)()
 solver.solve(coord)
 torch.cuda.synchronize()
 L.sc_dbg_pair_stamps(buf)
@@ -31,14 +31,27 @@ rc = L.sc_dbg_pair_stamps(buf)
 t = solver.last_timings()
 v = [int(x) for x in buf]
 steps = max(1, v[9])   # the stamps cover the common steps (pair_step_full) only
-names = ["wait+go [0]", "E loads issued / B: slot reads + store drain [1]", "D loads issued, E right + reflector [2,3]",
-         "column sums + u + D image [4,5]", "E left + D products [6]", "w [7]", "D update + stores"]
-print(f"rc {rc}  N = {n_atoms} x {B}: bulge chasing {t['bulge_chasing_ms']:.1f} ms, {steps} steps ({v[9]} with both teams at work), "
+names = ["wait + barrier [0]", "block reads (A: loads or landed image, B: slots + store drain) + [1]", "E right + reflector [2,3]",
+         "column sums + u + D image [4,5]", "E left + D products [6]", "w [7]", "D update (+ stores)"]
+print(f"rc {rc}  N = {n_atoms} x {B}  loader waves {os.environ.get('SPRINGCRAFT_PAIR_LOADER', '1')}: bulge chasing "
+      f"{t['bulge_chasing_ms']:.1f} ms, {v[8]} steps ({v[9]} common), "
       f"counters launches {solver.ctx.counter('chase_launches')} timeouts {solver.ctx.counter('chase_timeouts')}")
-tot = 0
+print(f"  {'cycles per common step':72s} {'thread 0 (A)':>12s} {'thread 256 (B)':>14s}")
+tot = [0, 0]
 for k, name in enumerate(names):
-    print(f"  {name:72s} {v[k] / steps:8.0f} cycles")
-    tot += v[k]
-print(f"  {'step':32s} {tot / steps:8.0f} cycles")
-print(f"  inside [1]: team A, E loads issued + vp read {v[12] / steps:.0f}; team B (thread 256): slot reads {v[10] / steps:.0f}, "
-      f"store drain {v[11] / steps:.0f}; team B, D update + stores {v[13] / steps:.0f} cycles")
+    b = v[16 + k] if k != 6 else v[16 + 13]
+    print(f"  {name:72s} {v[k] / steps:12.0f} {b / steps:14.0f}")
+    tot[0] += v[k]
+    tot[1] += b
+print(f"  {'step':72s} {tot[0] / steps:12.0f} {tot[1] / steps:14.0f}")
+print(f"  inside [1]: team A, block reads issued + vp read {v[12] / steps:.0f}; team B: slot reads {v[26] / steps:.0f}, "
+      f"store drain {v[27] / steps:.0f} cycles")
+print(f"  thread 0 inside [0]: {v[7] / steps:.0f} cycles in the block that reads the predecessor's counter, which it does in "
+      f"{v[10] / max(1, v[8]):.2f} of the steps")
+if v[40]:
+    ls = v[40]
+    ln = ["wait for this step's E pieces", "barrier [0]", "barriers [1] [2]", "wait for this step's D pieces", "barriers [3] [4]",
+          "E requests issued", "barriers [5] [6] [7]", "D requests issued (M0 write waits for the E pieces)"]
+    print(f"  loader wave 8, lane 0, {ls} steps that fetch and are served:")
+    for k, name in enumerate(ln):
+        print(f"    {name:70s} {v[32 + k] / ls:12.0f}")
