@@ -35,6 +35,11 @@ int sc_dbg_gemm_host(sc_ctx* ctx, const double* a, const double* b, double* c, i
 int sc_dbg_gemm3_host(sc_ctx* ctx, const double* a, const double* b, double* c, int count, int m, int n, int k, int layout,
                       int lower, double beta);
 
+/* x = sym(a) v through k_symm3 (csrc/symm3.hip), the band reduction's symmetric product as one role-split launch:
+ * `count` matrices a (m x m, column-major; read where (row | 1) >= col), v and x count x (m x 64) column-major, `split`
+ * K slices (summed on the host).  m a multiple of 16.  tests/test_gemm_gpu.py */
+int sc_dbg_symm3_host(sc_ctx* ctx, const double* a, const double* v, double* x, int count, int m, int split);
+
 /* `count` matrices of one shape on freshly allocated buffers, C += A B (lower != 0: the lower triangle, m == n), timed
  * through k_gemm3 (kernel 3; order 0 / 1: its flat / per-XCD super-tile order) or through k_gemm2 (kernel 2) with the same
  * records: ms_out = milliseconds per launch.  tools/gemm3_shapes.py */

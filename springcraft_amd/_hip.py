@@ -399,7 +399,7 @@ _PIN_POOL_MAX = 1 << 30
 _pin_free = {}          # bytes -> [address, ...]
 _pin_live = 0
 _pin_idle = 0
-_pin_lock = threading.Lock()
+_pin_lock = threading.RLock()   # re-entrant: a finalizer (_pin_release) may run inside a GC pass started under the lock
 
 
 def _pin_release(address, nbytes):

@@ -197,8 +197,13 @@ int ctx_create_impl(int device, void* stream, bool own, sc_ctx** out) {
   } else {
     ctx->stream = (hipStream_t)stream;
   }
+  // (d_zeros: the page of zeros k_symm3's loaders read -- symm3.hip --, zeroed here, long before any stream uses it)
   if (hipMalloc((void**)&ctx->d_status, kSpStatusWords * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_status, 0, kSpStatusWords * sizeof(unsigned long long)) != hipSuccess) {
+      hipMemset(ctx->d_status, 0, kSpStatusWords * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_zeros, 16384) != hipSuccess || hipMemset(ctx->d_zeros, 0, 16384) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SC_ERR_NOMEM;
@@ -356,6 +361,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->dc_aux) (void)hipFree(ctx->dc_aux);
   if (ctx->pinv_ws) (void)hipFree(ctx->pinv_ws);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
   for (int c = 0; c < 2; ++c) {
     if (ctx->h_stage[c]) (void)hipHostFree(ctx->h_stage[c]);
     if (ctx->h_stage_done[c]) (void)hipEventDestroy(ctx->h_stage_done[c]);
@@ -449,6 +455,7 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   else if (k == "chase_pair_fallbacks") *value = ctx->cnt_pair_fallbacks;
   else if (k == "xcd_count") *value = ctx->nxcd;
   else if (k == "gemm3_launches") *value = ctx->cnt_gemm3_launches;
+  else if (k == "symm3_launches") *value = ctx->cnt_symm3_launches;
   else if (k == "panel_coop_launches") *value = ctx->cnt_coop_launches;
   else if (k == "panel_coop_timeouts") *value = ctx->cnt_coop_timeouts;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;

@@ -76,6 +76,10 @@ struct sc_ctx {
   // k_gemm3 (gemm3.hip): whether its dynamic LDS size has been raised on this context's device (-1 not tried, 0 refused,
   // 1 set), and the launches it took
   int gemm3_attr = -1;
+  // k_symm3 (symm3.hip): a page of zeros its loaders point pieces at that must not count, and the launches it took
+  void* d_zeros = nullptr;
+  long long cnt_symm3_launches = 0;
+  bool gemm3_side_by_side = false;   // the caller runs parts of the batch on several streams (band reduction): see gemm3_would_take
   long long cnt_gemm3_launches = 0;
   // k_panel_coop (twostage.hip): dynamic LDS attribute of this device (-1 not tried, 0 refused, 1 set); coop_ok = 0
   // once a wait between its workgroups timed out (the context then keeps to the chunked panel launches)

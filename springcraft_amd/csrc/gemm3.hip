@@ -64,9 +64,10 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 struct G3Args {
   const GemmDesc* descs;
   int count, m, n, k;
-  int lower;      // records are lower_only with row_off = col_off = 0 and m == n: tiles above the diagonal are skipped
+  int lower;      // 1 / 2: records are lower_only (= this value) with row_off = col_off = 0 and m == n: tiles above the diagonal are skipped
   int beta_one;   // 1: C += A B; 0: C = A B
-  int order;      // tile order: 0 flat (column by column, workgroup wg takes tiles wg, wg + 256, ...), 1 strips of four tile rows, 32 consecutive tiles per XCD
+  int order;      // tile order: 0 flat (column by column, workgroup wg takes tiles wg, wg + nwg, ...), 1 strips of four tile rows, nwg / 8 consecutive tiles per XCD
+  int nwg;        // workgroups of the launch (a multiple of 8; 256 = one per CU)
 };
 
 template <int LAYOUT>   // kGemmAmBn (2), kGemmAmBk (0) or kGemmAkBk (1)
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
   // numbering for comparison.
   const int wg = (int)blockIdx.x;
   const int order = P.order;
-  const int w_first = order == 0 ? wg : 32 * (wg & 7) + (wg >> 3);   // this workgroup's tile number in round 0
+  const int nwg = P.nwg;
+  const int w_first = order == 0 ? wg : (nwg >> 3) * (wg & 7) + (wg >> 3);   // this workgroup's tile number in round 0
   struct It { int z, s, r, tm, tn; bool ok; };   // matrix, strip, number inside the strip -> (tm, tn)
   const int NS = order == 0 ? 1 : (TM + 3) >> 2;
   auto s_rows = [&](int st) { return order == 0 ? TM : min(4, TM - 4 * st); };
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
   };
   auto it_next = [&](It& it) {
     if (!it.ok) return;
-    it.r += 256;
+    it.r += nwg;
     it_norm(it);
   };
   // (no count of the workgroup's tiles up front -- a walk over all of them is some hundred scalar iterations per wave
@@ -300,7 +302,10 @@ __global__ __launch_bounds__(1024, 1) void k_gemm3(G3Args P) {
     // diagonal (a pair of rows that straddles it stores its second row alone)
     auto out_col = [&](const CT& t, int j) {
       if (j >= t.ncol) return;
-      const int rel = lower ? max(0, t.colg + j - t.row0) : 0;   // first row of the tile that is stored
+      // first row of the tile that is stored (lower = 2: from the even row on -- the first super-diagonal entry of every
+      // even row is kept as well, symm3.hip; the tile's first row is even)
+      const int cj = lower == 2 ? ((t.colg + j) & ~1) : t.colg + j;
+      const int rel = lower ? max(0, cj - t.row0) : 0;
       if (rel >= t.mrem) return;
       const d2v v = *(const d2v*)(img + j * kRow);
       const unsigned long long a = t.base + (unsigned long long)j * t.col;
@@ -517,7 +522,7 @@ int g_gemm3_order = -1;          // debugging (sc_dbg_gemm3_bench): tile order, 
 // caller uses launch_gemm_f64).  Taken: layout kGemmAmBn / kGemmAmBk, alpha = 1, beta in {0, 1}, k a multiple of 16 and
 // >= 128, m (and n for kGemmAmBn) even, pointers and leading dimensions that keep 16-byte alignment (aligned16: the
 // caller knows its records), enough tiles to give every CU a few.  lower: as launch_gemm_f64's lower_grid.
-bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, bool lower, double alpha, double beta,
+bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, int lower, double alpha, double beta,
                       bool aligned16) {
   static const int env = [] { const char* e = getenv("SPRINGCRAFT_GEMM3"); return e ? atoi(e) : 1; }();
   if (env == 0 || count <= 0) return false;
@@ -531,8 +536,12 @@ bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, b
   // with few tiles --: left to k_gemm2 unless SPRINGCRAFT_GEMM3_LOWER = 1)
   // For a few large matrices it wins (one n = 24000 matrix, config C5: 186 -> 178 ms of trailing updates per solve): there
   // the two half batches on two streams, whose panel QRs hide beside k_gemm2's workgroups, do not exist.
+  // Round 6: with the two half batches on two streams (ctx->gemm3_side_by_side, set by the band reduction) it takes the
+  // update after all -- on 224 workgroups instead of 256, which leaves an eighth of the CUs to the other half's panel QR
+  // and small products: C3 step 2200 -> 2150-2160 ms (same box, tools/quick_env_ab.sh: 208 / 216 / 224 workgroups 2157-2177 /
+  // 2149-2169 / 2145-2166, 232 / 240: 2190-2210, 256: 2191-2196; profiles/r06_syr2k_wgs.txt).
   static const int env_lower = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_LOWER"); return e ? atoi(e) : -1; }();
-  if (lower && !g_gemm3_any_size && (env_lower == 0 || (env_lower < 0 && count >= 8))) return false;
+  if (lower && !g_gemm3_any_size && (env_lower == 0 || (env_lower < 0 && count >= 8 && !ctx->gemm3_side_by_side))) return false;
   // (the kernel's tile order is built on 8 XCDs x 32 workgroups: a device -- or a partition -- with fewer CUs stays on k_gemm2)
   if (ctx->num_cus < 256 || ctx->gemm3_attr == 0) return false;
   const long long TM = (m + 127) / 128, TN = (n + 63) / 64;
@@ -543,7 +552,7 @@ bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, b
   return total <= 0x3fffffffLL;
 }
 
-int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
+int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, int lower,
                          double alpha, double beta, bool aligned16) {
   if (!gemm3_would_take(ctx, count, m, n, k, layout, lower, alpha, beta, aligned16)) return 1;
   if (ctx->gemm3_attr < 0) {   // per device, hence per context
@@ -557,8 +566,12 @@ int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, 
   }
   if (ctx->gemm3_attr != 1) return 1;
   static const int env_order = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_ORDER"); return e ? atoi(e) : 1; }();
-  G3Args A{d_desc, count, m, n, k, lower ? 1 : 0, beta != 0.0 ? 1 : 0, g_gemm3_order >= 0 ? g_gemm3_order : env_order};
-  const unsigned grid = 256u;
+  // Workgroups of a lower-only launch (the band reduction's trailing update), SPRINGCRAFT_GEMM3_LOWER_WGS (a multiple of
+  // 8, default 256): fewer than one per CU leaves CUs to the other half batch's panel QR that runs beside it
+  static const int env_lower_wgs = [] { const char* e = getenv("SPRINGCRAFT_GEMM3_LOWER_WGS"); return e ? std::max(8, std::min(256, atoi(e) / 8 * 8)) : 0; }();
+  const int nwg = lower ? (env_lower_wgs > 0 ? env_lower_wgs : (ctx->gemm3_side_by_side ? 224 : 256)) : 256;
+  G3Args A{d_desc, count, m, n, k, lower, beta != 0.0 ? 1 : 0, g_gemm3_order >= 0 ? g_gemm3_order : env_order, nwg};
+  const unsigned grid = (unsigned)nwg;
   if (layout == kGemmAmBn) hipLaunchKernelGGL(k_gemm3<kGemmAmBn>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
   else if (layout == kGemmAkBk) hipLaunchKernelGGL(k_gemm3<kGemmAkBk>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
   else hipLaunchKernelGGL(k_gemm3<kGemmAmBk>, dim3(grid), dim3(1024), kG3Lds, ctx->stream, A);
@@ -604,7 +617,7 @@ extern "C" int sc_dbg_gemm3_host(sc_ctx* ctx, const double* a, const double* b, 
   fail(hipMemcpy(dd, h.data(), sizeof(GemmDesc) * (size_t)count, hipMemcpyHostToDevice));
   if (rc == SC_OK) {
     g_gemm3_any_size = true;
-    const int took = launch_gemm3_uniform(ctx, dd, count, m, n, k, layout, lower != 0, 1.0, beta, true);
+    const int took = launch_gemm3_uniform(ctx, dd, count, m, n, k, layout, lower, 1.0, beta, true);
     g_gemm3_any_size = false;
     if (took != SC_OK) rc = sc_set_error(ctx, SC_ERR_INVALID_ARG, "k_gemm3 does not take m %d n %d k %d layout %d", m, n, k, layout);
     fail(hipStreamSynchronize(ctx->stream));
@@ -659,7 +672,7 @@ extern "C" int sc_dbg_gemm3_bench(sc_ctx* ctx, int count, int m, int n, int k, i
     if (kernel == 3) {
       g_gemm3_any_size = true;
       g_gemm3_order = order;
-      const int took = launch_gemm3_uniform(ctx, dd, count, m, n, k, layout, lower != 0, 1.0, 1.0, true);
+      const int took = launch_gemm3_uniform(ctx, dd, count, m, n, k, layout, lower, 1.0, 1.0, true);
       g_gemm3_any_size = false;
       g_gemm3_order = -1;
       return took == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;

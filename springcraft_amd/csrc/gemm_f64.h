@@ -27,7 +27,7 @@ struct GemmDesc {
   const int* a_kidx;      // optional gather on A's k axis: A(i,k) = a[i*sa_i + a_kidx[k]*sa_k]
   const int* b_kidx;      // optional gather on B's k axis: B(k,j) = b[b_kidx[k]*sb_k + j*sb_j]
   const int* c_jidx;      // optional scatter on C's column axis: C(:, j) lives at column c_jidx[j]
-  int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K)
+  int lower_only;         // 1: store only elements with (row + row_off) >= (col + col_off) (SYR2K); 2: ((row + row_off) | 1) >= ...
   int row_off, col_off;
   long long split_stride; // split-K launches: slice s writes alpha*partial to C + s*split_stride (beta ignored)
   int a_tri;              // launches with tri = true: 1: A(i,k) counts only for i >= k; 2: only for k > i
@@ -56,8 +56,16 @@ int launch_gemm_f64(sc_ctx* ctx, const GemmDesc* d_desc, int count, int max_m, i
 // 0 or 1 -- callers fold a sign into an operand --; aligned16: every operand pointer and leading dimension of the
 // records keeps 16-byte alignment (the host built them).  SPRINGCRAFT_GEMM3 = 0 switches it off, = 2 takes every
 // launch that qualifies whatever its size (tests).
-int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, bool lower,
+// lower: 0 all of C; 1 the lower triangle (as lower_only = 1 with row_off = col_off = 0, m == n); 2 as lower_only = 2.
+int launch_gemm3_uniform(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int n, int k, int layout, int lower,
                          double alpha, double beta, bool aligned16);
 // (the launcher's decision without the launch: callers that lay out their records differently for the two kernels)
-bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, bool lower, double alpha, double beta,
+bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, int lower, double alpha, double beta,
                       bool aligned16);
+
+// The symmetric product X = A V (A lower stored, V and X with 64 columns) of the band reduction on k_symm3 (symm3.hip):
+// SC_OK when it took the launch, 1 when the launch is not one it takes (m a multiple of 16, 16-byte aligned operands,
+// enough tiles; SPRINGCRAFT_SYMM3 = 0 switches it off, = 2 takes every launch that qualifies).  split: K slices, slice s
+// into c + s * split_stride.  The kernel reads A where (row | 1) >= col: see its header for what the writers of A keep.
+int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int split, bool aligned16);
+bool symm3_would_take(sc_ctx* ctx, int count, int m, int split, bool aligned16);

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
   const double alpha = D.alpha;
   const double beta = split_k > 1 ? 0.0 : D.beta;
   const long long ldc = D.ldc;
-  const bool lower = D.lower_only != 0;
+  const bool lower = D.lower_only != 0, lower2 = D.lower_only == 2;
   const int roff = D.row_off, coff = D.col_off;
 
   // beta * C goes straight into the accumulators (scaled by 1/alpha); its loads fly together with the first tiles
@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm2(const GemmDesc* __restrict__ d
       for (int mi = 0; mi < MT; ++mi) {
         const int row = m0 + wm * WM + mi * 16 + fr;
         if (row >= M) continue;
-        if (lower && (row + roff) < (col + coff)) continue;
+        // (lower_only = 2: also the first super-diagonal entry of every even row, which k_symm3 reads -- symm3.hip)
+        if (lower && (lower2 ? ((row + roff) | 1) : (row + roff)) < (col + coff)) continue;
         ccol[row] = alpha * acc[ni][mi][r];
       }
     }

@@ -18,6 +18,11 @@
 
 namespace {
 
+// n m rounded up to a multiple of four doubles: the 32-byte backward records start at 2 nm4 and every matrix' share of the
+// workspace is a multiple of 32 bytes, so the 16- and 32-byte accesses are aligned whatever the parity of n and m (ADVICE
+// round 5: with n m odd the records of batch members >= 1 sat on 8-byte boundaries, which gfx9 tolerates by splitting)
+__host__ __device__ inline size_t stein_nm4(int n, int m) { return ((size_t)n * m + 3) / 4 * 4; }
+
 constexpr double kEpsS = 2.220446049250313e-16;
 
 // One WAVE per requested eigenvalue: multisection.  Every round the 64 lanes count the eigenvalues below 64 equally
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64) void k_stein(const double* __restrict__ tri_all
   const double* w = w_all + (size_t)blockIdx.y * stride_w;
   double* fac = fac_all + (size_t)blockIdx.y * stride_fac;
   d2v* F = reinterpret_cast<d2v*>(fac);                              // [n][m]
-  d4v* B = reinterpret_cast<d4v*>(fac + (size_t)2 * n * m);          // [n][m]
+  d4v* B = reinterpret_cast<d4v*>(fac + 2 * stein_nm4(n, m));          // [n][m]
   double* X = x_all + (size_t)blockIdx.y * stride_x + (size_t)j * n;   // column j of X (n x m, ld n)
 
   const double tiny = kEpsS * tnorm;
@@ -396,9 +401,8 @@ __global__ __launch_bounds__(256) void k_chol_inv(double* __restrict__ g_all, lo
 }  // namespace
 
 size_t stein_workspace_doubles(int n, int m) {
-  // factors 6 n m (16-byte forward + 32-byte backward records) + second X buffer n m + Gram slices 32 m^2 + Rinv m^2
-  // (+ alignment)
-  return (size_t)7 * n * m + (size_t)33 * m * m + 64;
+  // factors 6 nm4 (16-byte forward + 32-byte backward records) + second X buffer nm4 + Gram slices 32 m^2 + Rinv m^2
+  return (7 * stein_nm4(n, m) + (size_t)33 * m * m + 64 + 3) / 4 * 4;
 }
 
 // Eigenvalues il..iu (0-based, inclusive) into d_w (batch, m) and eigenvectors of T into d_x (batch, n, m
@@ -431,8 +435,8 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
   for (int round = 0; round < 2; ++round) {
     for (int b = 0; b < batch; ++b) {
       double* ws = d_ws + (size_t)b * stride_ws;
-      double* x2 = ws + (size_t)6 * n * m;
-      double* gram = ws + (size_t)7 * n * m;
+      double* x2 = ws + 6 * stein_nm4(n, m);
+      double* gram = ws + 7 * stein_nm4(n, m);
       double* rinv = gram + (size_t)32 * m * m;
       const double* xin = (round == 0 ? d_x + (size_t)b * stride_x : x2);
       double* xout = (round == 0 ? x2 : d_x + (size_t)b * stride_x);
@@ -452,7 +456,7 @@ int stein_batched(sc_ctx* ctx, int n, int batch, const double* d_tri_ws, const T
     SC_TRY(sc_stage_upload(ctx, d_descs, h.data(), h.size() * sizeof(GemmDesc)));
     SC_TRY(launch_gemm_f64(ctx, d_descs, batch, m, m, kGemmTile, splits, false, false, kGemmAkBk));
     {
-      double* gram0 = d_ws + (size_t)7 * n * m;
+      double* gram0 = d_ws + 7 * stein_nm4(n, m);
       hipLaunchKernelGGL(k_chol_inv, dim3((unsigned)batch), dim3(256), 0, st, gram0, stride_ws, m, splits,
                          gram0 + (size_t)32 * m * m, stride_ws);
     }

@@ -499,7 +499,9 @@ __global__ __launch_bounds__(256) void k_scale_lower(double* __restrict__ a_all,
   const size_t total = (size_t)n * n;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
-    if (r >= c) A[idx] = bad ? 0.0 : A[idx] * f;   // (a matrix with non-finite entries is solved as the zero matrix)
+    // (r | 1: also the first super-diagonal entry of every even row, which the band reduction keeps equal to its mirror
+    // image for k_symm3 -- symm3.hip)
+    if ((r | 1) >= c) A[idx] = bad ? 0.0 : A[idx] * f;   // (a matrix with non-finite entries is solved as the zero matrix)
   }
 }
 

@@ -4037,9 +4037,24 @@ __global__ __launch_bounds__(256) void k_bt2_wave(const double* __restrict__ sb_
 // K slices of the SYMM X = A22 V: with few matrices its launch has only n / 64 tiles per matrix, each walking a K range of
 // up to n (longest first, but the longest IS the critical path): slices of the K range give the launch 2 - 8 times the
 // workgroups and a fraction of the critical path.  Config C5 (one 24000 x 24000 matrix): 596 -> 307 ms.
+// Whether the band reduction of order-n matrices runs its SYMM on k_symm3 (symm3.hip; the launcher may still decline a
+// panel -- too few tiles late in the reduction -- which then takes the two triangular-operand launches below)
+bool symm3_for(int n) {
+  static const int env = [] { const char* e = getenv("SPRINGCRAFT_SYMM3"); return e ? atoi(e) : 1; }();
+  return env != 0 && n >= 512 && (n & 1) == 0;
+}
+
 int symm_split_for(int n, int batch) {
   static const int env = [] { const char* e = getenv("SPRINGCRAFT_SYMM_SPLIT"); return e ? atoi(e) : 0; }();
   if (env >= 1) return std::min(env, 16);
+  if (symm3_for(n)) {
+    // k_symm3: a work item is (128-row tile, K slice), all of equal length; 256 persistent workgroups want a few rounds
+    // of them (a launch holds half the batch from 32 matrices on: the two half batches run on two streams)
+    const long long items = (long long)((n + 127) / 128) * (batch >= 32 ? batch / 2 : batch);
+    // (C5, one n = 24000 matrix = 188 tile rows, tools/r06_cfgs.sh: 3 / 4 / 5 / 6 / 8 slices 1143 / 1114 / 1105 / 1092 / 1083 ms)
+    if (items >= 768) return 1;
+    return (int)std::min<long long>(16, (1536 + items - 1) / items);
+  }
   const long long tiles = (long long)batch * ((n + 63) / 64);
   if (tiles >= 1024 || n < 2048) return 1;
   // (one 24000 x 24000 matrix: 3 slices 338 ms, 6 slices 307 ms, 8 slices 378 ms of SYMM time)
@@ -4050,8 +4065,10 @@ int symm_split_for(int n, int batch) {
   // (n = 6000, one to four matrices: 6, 7 and 9 slices within 1 %).
   // The middle regime follows the same rule (`tools/r05_symm_mid.sh`, 6 x n = 6000 = 564 tiles: 4 slices 38.9 ms of SYMM
   // per step, 5 slices 31.0): an even count takes the next odd one.
+  // (ceil(2048 / tiles) is 3 for 683 .. 1023 tiles, 4 for 512 .. 682, 5 for 410 .. 511, 6 and more below: the only even
+  // count the rule replaces is the measured 4 -> 5)
   const long long s0 = std::min<long long>(6, (2048 + tiles - 1) / tiles);
-  return s0 >= 6 ? 9 : (int)(s0 | 1);
+  return s0 >= 6 ? 9 : (s0 == 4 ? 5 : (int)s0);
 }
 
 size_t sb_slab_doubles(int n, int batch, SbLayout* out) {
@@ -4189,7 +4206,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       R.b = sb + SL.wv + r0; R.sb_k = n; R.sb_j = 1;
       R.c = a22; R.ldc = n;
       R.m = m; R.n = m; R.k = rl == 2 ? 4 * kB : 2 * kB; R.alpha = 1.0; R.beta = 1.0;   // b = -[W|V]
-      R.lower_only = 1;
+      // (with k_symm3 in use the trailing updates also keep the first super-diagonal entry of every even row: symm3.hip)
+      R.lower_only = symm3_for(n) ? 2 : 1;
       g[5] = R;
       // first of a pair: only the next panel's 64 columns (and the band block above them) get this panel's update now
       GemmDesc D = R;
@@ -4269,6 +4287,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       SC_HIP(ctx, hipMemsetAsync(ctx->dc_aux, 0, ctl_bytes + rec_bytes, st));
     }
   }
+  // k_symm3 writes X into the X1 block of [X1 | X2 | V]; the X2 block reads zero for the whole solve (the panels at the
+  // end of the reduction that fall back to the two triangular-operand launches rewrite their rows of it themselves)
+  const bool use_symm3 = symm3_for(n) && (n & 1) == 0;
+  if (use_symm3)
+    for (int b = 0; b < batch; ++b)
+      SC_HIP(ctx, hipMemsetAsync(d_sb_ws + (size_t)b * SL.slab + SL.xv + (size_t)kB * n, 0, sizeof(double) * (size_t)kB * n, st));
   // One panel of the matrices [lo, hi) on `ps`: QR of the panel, X = A22 V, the small products, W, the trailing update
   // its role asks for (single: SYR2K; first of a pair: the next panel's columns only; second: the joint update).
   auto run_panel = [&](int p, int lo, int hi, hipStream_t ps, bool timed) -> int {
@@ -4346,10 +4370,17 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     if (timed) t_qr.stop();
     const GemmDesc* g = d_descs + (size_t)p * kDescKinds * batch;   // [kind][batch]
     if (timed) t_symm.start();
-    SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAmBk));           // X1 = L V
-    SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAkBk));   // X2 = strict(L)^T V
-    if (SL.symm_split > 1)
-      hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), 2 * kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
+    // X = A22 V: one launch of k_symm3 (X into X1; X2 was zeroed for the whole solve) while the panel has enough tiles
+    // for it, else X1 = L V and X2 = strict(L)^T V by two triangular-operand launches of k_gemm2
+    if (use_symm3 && launch_symm3(ctx, g + lo, nb, m, SL.symm_split, /*aligned16=*/true) == SC_OK) {
+      if (SL.symm_split > 1)
+        hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
+    } else {
+      SC_TRY(launch_gemm_f64(ctx, g + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAmBk));           // X1 = L V
+      SC_TRY(launch_gemm_f64(ctx, g + batch + lo, nb, m, kB, kGemmTile, SL.symm_split, false, true, kGemmAkBk));   // X2 = strict(L)^T V
+      if (SL.symm_split > 1)
+        hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), 2 * kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
+    }
     if (rl == 2) {   // the trailing matrix has not seen the first panel's update yet: X1 -= [V1|W1] ([W1|V1]^T V2)
       SC_TRY(launch_gemm_f64(ctx, g + 7 * batch + lo, nb, 2 * kB, kB, kGemmTile, kSmallSplit, false, false, kGemmAkBk));
       hipLaunchKernelGGL(k_sum_p2, dim3((unsigned)(2 * kB * kB / 256), (unsigned)nb), dim3(256), 0, ps, sb_h, SL);
@@ -4369,7 +4400,7 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
       SC_TRY(launch_gemm_f64(ctx, g + 6 * batch + lo, nb, m, kB, kGemmTile, 1, false, false, kGemmAmBn));
     else
       // (records of one launch share (m, m, K); operands start at even rows of buffers with even leading dimension n)
-      if (launch_gemm3_uniform(ctx, g + 5 * batch + lo, nb, m, m, rl == 2 ? 4 * kB : 2 * kB, kGemmAmBn, /*lower=*/true, 1.0, 1.0,
+      if (launch_gemm3_uniform(ctx, g + 5 * batch + lo, nb, m, m, rl == 2 ? 4 * kB : 2 * kB, kGemmAmBn, /*lower=*/use_symm3 ? 2 : 1, 1.0, 1.0,
                                /*aligned16=*/(n & 1) == 0 && (r0 & 1) == 0) != SC_OK)
         SC_TRY(launch_gemm_f64(ctx, g + 5 * batch + lo, nb, m, m, kGemmTile, 1, false, false, kGemmAmBn, /*lower_grid=*/true));
     if (timed) t_syr2k.stop();
@@ -4383,6 +4414,11 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   const int s1_want = env_s1 > 0 ? env_s1 : ((batch >= 32 && !prof) ? 2 : 1);
   const int s1_parts = std::max(1, std::min(s1_want, std::min(batch, 4)));
   if (s1_parts > 1) {
+    struct SideBySide {   // (k_gemm3 leaves CUs to the other parts' kernels while this is set: gemm3_would_take)
+      sc_ctx* c;
+      explicit SideBySide(sc_ctx* c_) : c(c_) { c->gemm3_side_by_side = true; }
+      ~SideBySide() { c->gemm3_side_by_side = false; }
+    } side_by_side(ctx);
     SC_TRY(sc_aux_stream(ctx));
     SC_TRY(sc_side_streams(ctx, s1_parts - 1));
     SC_HIP(ctx, hipEventRecord(ctx->aux_fork, st));
@@ -4438,8 +4474,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     // SPRINGCRAFT_PAIR_LOADER = 1: the pair form with its loader waves (k_bulge_pair<1>, 768 threads: measured, slower --
     // profiles/r06_pair_stamps.txt; default: the 512-thread form)
     static const bool pair_loader = [] { const char* e = getenv("SPRINGCRAFT_PAIR_LOADER"); return e && atoi(e) != 0; }();
-    // SPRINGCRAFT_PAIR_EARLY = 0: the pair form looks at its predecessor when a step begins (round 4) instead of a step ahead
-    static const int pair_early = [] { const char* e = getenv("SPRINGCRAFT_PAIR_EARLY"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+    // SPRINGCRAFT_PAIR_EARLY = 1: the pair form looks at its predecessor a step ahead (measured: 317-319 against 312-313 ms
+    // at 64 x n = 6000, profiles/r06_pair_ab.txt; default: when a step begins, as in round 4)
+    static const int pair_early = [] { const char* e = getenv("SPRINGCRAFT_PAIR_EARLY"); return (e && atoi(e) != 0) ? 1 : 0; }();
     if (ctx->pair_attr < 0)   // per device, hence per context: the caller made ctx->device current
       ctx->pair_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bulge_pair<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes) == hipSuccess &&

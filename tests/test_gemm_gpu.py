@@ -124,7 +124,9 @@ def gemm3():
         ref = A @ B + (beta * C0 if beta != 0.0 else 0.0)
         if lower:
             ii, jj = np.indices((m, n))
-            ref = np.where(ii >= jj, ref, C0)      # entries above the diagonal keep their old value
+            # entries above the diagonal keep their old value (lower = 2: but for the first super-diagonal entry of every
+            # even row, which the band reduction keeps for k_symm3)
+            ref = np.where((ii | 1) >= jj if lower == 2 else ii >= jj, ref, C0)
         tol = 4 * np.finfo(float).eps * k * 3
         err = np.abs(got - ref).max()
         assert err <= tol, (count, m, n, k, layout, lower, beta, err, tol)
@@ -138,7 +140,10 @@ def gemm3():
                          1.0, beta, 0)
                 assert rc == 0
                 ref2 = c2 if not lower else np.where(np.indices((m, n))[0] >= np.indices((m, n))[1], c2, C0[z])
-                if layout != 2 or lower:            # (sc_dbg_gemm_host's NT mode is lower_only)
+                if lower == 2:                      # (sc_dbg_gemm_host's NT mode keeps the plain lower triangle)
+                    ii, jj = np.indices((m, n))
+                    assert np.array_equal(got[z][ii >= jj], ref2[ii >= jj])
+                elif layout != 2 or lower:          # (sc_dbg_gemm_host's NT mode is lower_only)
                     assert np.array_equal(got[z], ref2), (m, n, k, layout, lower, np.abs(got[z] - ref2).max())
         return got
 
@@ -156,9 +161,11 @@ def test_gemm3_shapes(gemm3, layout, m, n, k, beta):
 
 @pytest.mark.parametrize("m", [64, 126, 128, 130, 700, 1030, 2000])
 @pytest.mark.parametrize("k", [128, 256])
-def test_gemm3_lower_only(gemm3, m, k):
-    """The trailing update of the band reduction: lower triangle only, entries above the diagonal untouched."""
-    gemm3(3, m, m, k, 2, lower=1, seed=m)
+@pytest.mark.parametrize("lower", [1, 2])
+def test_gemm3_lower_only(gemm3, m, k, lower):
+    """The trailing update of the band reduction: lower triangle only, entries above the diagonal untouched (lower = 2: plus
+    the first super-diagonal entry of every even row)."""
+    gemm3(3, m, m, k, 2, lower=lower, seed=m)
 
 
 def test_gemm3_many_tiles_per_workgroup(gemm3):
@@ -182,3 +189,54 @@ def test_gemm3_declines_what_it_does_not_take(gemm3):
     for m, n, k, layout in [(129, 64, 128, 0), (128, 64, 120, 0), (128, 64, 64, 0), (128, 65, 128, 2)]:
         rc = L.sc_dbg_gemm3_host(ctx.handle, z.ctypes.data, z.ctypes.data, z.ctypes.data, 1, m, n, k, layout, 0, C.c_double(1.0))
         assert rc != 0, (m, n, k, layout)
+
+
+# ---- k_symm3 (csrc/symm3.hip): X = sym(A) V with only (row | 1) >= col of A read
+@pytest.fixture(scope="module")
+def symm3():
+    from springcraft_amd import _hip
+
+    L = _hip.lib()
+    ctx = _hip.context()
+    fn = L.sc_dbg_symm3_host
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+    def run(count, m, split=1, seed=0):
+        rs = np.random.RandomState(seed + m + count)
+        out = []
+        A = rs.uniform(-1, 1, (count, m, m))
+        S = np.tril(A) + np.tril(A, -1).transpose(0, 2, 1)          # the symmetric matrices the lower triangles stand for
+        V = rs.uniform(-1, 1, (count, m, 64))
+        # what the kernel is handed: the lower triangle, the first super-diagonal entry of every even row equal to its
+        # mirror image (what the band reduction keeps), NaN everywhere else above the diagonal -- nothing of it may be read
+        stored = np.where(np.tril(np.ones((m, m), dtype=bool)), S, np.nan)
+        ev = np.arange(0, m - 1, 2)
+        stored[:, ev, ev + 1] = S[:, ev, ev + 1]
+        a = np.ascontiguousarray(stored.transpose(0, 2, 1))         # column-major per matrix
+        v = np.ascontiguousarray(V.transpose(0, 2, 1))
+        x = np.empty_like(v)
+        rc = fn(ctx.handle, a.ctypes.data, v.ctypes.data, x.ctypes.data, count, m, split)
+        assert rc == 0, rc
+        X = x.transpose(0, 2, 1)
+        ref = S @ V
+        tol = 4 * np.finfo(float).eps * m
+        err = np.abs(X - ref).max()
+        assert np.isfinite(X).all() and err <= tol * max(1.0, np.abs(ref).max()), (count, m, split, err)
+        return out
+
+    return run
+
+
+@pytest.mark.parametrize("count,m", [(1, 256), (3, 384), (2, 1024), (1, 2000), (5, 784), (40, 512), (2, 1000), (1, 2102),
+                                     (3, 258)])
+def test_symm3_whole_k(symm3, count, m):
+    """One launch, every tile all m columns: full tiles, a partial last tile (m = 2000, 784), orders that are no multiple
+    of 16 (a last K step that reaches beyond the matrix), one to many tiles per workgroup."""
+    symm3(count, m)
+
+
+@pytest.mark.parametrize("count,m,split", [(1, 1024, 3), (1, 2000, 5), (2, 768, 2), (1, 4096, 9), (1, 2936, 3)])
+def test_symm3_k_slices(symm3, count, m, split):
+    """K slices: a slice may start behind a tile's diagonal block or end in front of it."""
+    symm3(count, m, split)
