@@ -39,6 +39,13 @@ int sc_dbg_gemm3_host(sc_ctx* ctx, const double* a, const double* b, double* c, 
  * `count` matrices a (m x m, column-major; read where (row | 1) >= col), v and x count x (m x 64) column-major, `split`
  * K slices (summed on the host).  m a multiple of 16.  tests/test_gemm_gpu.py */
 int sc_dbg_symm3_host(sc_ctx* ctx, const double* a, const double* v, double* x, int count, int m, int split);
+/* Library built with -DSYMM3_STAMPS (else returns 1): out4 = shader cycles the first loader wave of every k_symm3 workgroup
+ * spent {waiting for its LDS-DMA group to land, at the step barriers, in its loop}, and the steps it waited in; reset by
+ * the call.  tools/r06_symm3_stamps.sh */
+int sc_dbg_symm3_stamps(unsigned long long* out4);
+/* `count` random matrices of order m (even, >= 256), X = A V through k_symm3 with `split` K slices, `iters` timed launches:
+ * average milliseconds per launch.  tools/symm3_bench.py */
+int sc_dbg_symm3_bench(sc_ctx* ctx, int count, int m, int split, int iters, double* ms_out);
 
 /* `count` matrices of one shape on freshly allocated buffers, C += A B (lower != 0: the lower triangle, m == n), timed
  * through k_gemm3 (kernel 3; order 0 / 1: its flat / per-XCD super-tile order) or through k_gemm2 (kernel 2) with the same

@@ -32,6 +32,11 @@
 //     from a scalar base.
 //   * Every tile has m / 16 + 8 K steps: no triangular imbalance, no "longest first" order, no second launch, no sum of
 //     X1 and X2 (the callers keep their [X1 | X2 | V] operand: X lands in X1, X2 is zeroed once per solve).
+//   * Tried and dropped (profiles/r06_symm3.txt): a ring of five slots with three K steps in flight, twelve loader waves
+//     and the MFMA waves storing their result themselves (no C image).  The loaders then never wait for a group (0.8 %
+//     of their loop instead of 9.8 %) and the product is no faster (same box: 2137-2140 against 2124-2136 ms per C3 step):
+//     neither the memory latency nor the fetched bytes bound it -- with every column of A redirected to one hot column
+//     the launch set takes 180 instead of 190 ms -- the MFMA waves issue at 0.67-0.70 of their pipes' time either way.
 // K slices for launches with few tiles (split > 1): slice s runs the steps [s KS / split, (s + 1) KS / split) of every tile
 // into its own copy of X (GemmDesc::split_stride); k_sum_xslices adds them up as before.
 //
@@ -62,6 +67,12 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Diagnostic build (-DSYMM3_STAMPS, tools/r06_symm3_stamps.sh): cycles the first loader wave of every workgroup spends
+// waiting for its group to land (s_waitcnt vmcnt(0)), at the step barrier, and in the loop; steps it waited in.
+#ifdef SYMM3_STAMPS
+__device__ unsigned long long g_symm3_stamps[4];
+#endif
+
 struct S3Args {
   const GemmDesc* descs;   // a = A(0, 0) of the symmetric matrix (lower stored, column stride sa_k), b = V (sb_k = 1, column
                            // stride sb_j), c = X (ldc), split_stride
@@ -70,6 +81,8 @@ struct S3Args {
   int nwg;                 // workgroups of the launch (a multiple of 8)
   const double* zeros;     // middle of a page of zeros (+- 4 KB readable)
   int gb[17];              // slice s runs the K steps gb[s] .. gb[s + 1] - 1 of a tile (gb[split] = ceil(m / 16) + 8)
+  int hot;                 // diagnostic (SPRINGCRAFT_SYMM3_DBG_HOT, results wrong): bit 0: every column of A reads column 0 (L2
+                           // hits); bit 1: no step takes the per-lane-address path
 };
 
 __global__ __launch_bounds__(1024, 1) void k_symm3(S3Args P) {
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(1024, 1) void k_symm3(S3Args P) {
         I0 = lt.tm * 128;
         mrem = min(128, m - I0);
         sw = g_sw(lt);
-        lda8 = uni64((unsigned long long)D.sa_k * 8ull);
+        lda8 = (P.hot & 1) ? 0ull : uni64((unsigned long long)D.sa_k * 8ull);
         ldb8 = uni64((unsigned long long)D.sb_j * 8ull);
         a8 = uni64((unsigned long long)(size_t)D.a);
         b8 = uni64((unsigned long long)(size_t)D.b);
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(1024, 1) void k_symm3(S3Args P) {
       const int slot_l = l_slot;
       const bool am = g < sw;
       const int k0 = am ? 16 * g : 16 * (g - 8);
-      const bool special = (g >= sw - 8 && g < sw + 8) || k0 + 16 > m;
+      const bool special = !(P.hot & 2) && ((g >= sw - 8 && g < sw + 8) || k0 + 16 > m);
       const int I0_now = I0;
       // advance to this wave's next group
       l_g += 2;
@@ -246,15 +259,46 @@ __global__ __launch_bounds__(1024, 1) void k_symm3(S3Args P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int c_g = g_lo(cur), c_hi = g_hi(cur);
+#ifdef SYMM3_STAMPS
+    unsigned long long st_wait = 0, st_bar = 0, st_n = 0, st_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
+#endif
     for (int g = 0; cur.ok; ++g) {
       if ((g & 1) == parity) {
         if (lt.ok) issue_group();   // group g + 2
       } else {
+#ifdef SYMM3_STAMPS
+        unsigned long long ta, tb;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta)::"memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
+        st_wait += tb - ta;
+        ++st_n;
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       }
+#ifdef SYMM3_STAMPS
+      unsigned long long tc, td;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc)::"memory");
       __builtin_amdgcn_s_barrier();
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td)::"memory");
+      st_bar += td - tc;
+#else
+      __builtin_amdgcn_s_barrier();
+#endif
       if (++c_g == c_hi) { it_next(cur); if (cur.ok) { c_g = g_lo(cur); c_hi = g_hi(cur); } }
     }
+#ifdef SYMM3_STAMPS
+    if (d == 0 && lane == 0) {
+      unsigned long long te;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te)::"memory");
+      atomicAdd(&g_symm3_stamps[0], st_wait);
+      atomicAdd(&g_symm3_stamps[1], st_bar);
+      atomicAdd(&g_symm3_stamps[2], te - st_t0);
+      atomicAdd(&g_symm3_stamps[3], st_n);
+    }
+#endif
     __builtin_amdgcn_s_barrier();   // (the MFMA waves' last swap)
     return;
   }
@@ -476,9 +520,11 @@ int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int spli
   // QR and small products then find CUs beside this launch, as for k_gemm3's trailing update; SPRINGCRAFT_SYMM3_WGS)
   static const int env_wgs = [] { const char* e = getenv("SPRINGCRAFT_SYMM3_WGS"); return e ? std::max(8, std::min(256, atoi(e) / 8 * 8)) : 0; }();
   const int nwg = env_wgs > 0 ? env_wgs : (ctx->gemm3_side_by_side ? 224 : 256);
-  S3Args A{d_desc, count, m, split, nwg, reinterpret_cast<const double*>(reinterpret_cast<const char*>(ctx->d_zeros) + 8192), {0}};
+  S3Args A{d_desc, count, m, split, nwg, reinterpret_cast<const double*>(reinterpret_cast<const char*>(ctx->d_zeros) + 8192), {0}, 0};
   const int ks_all = (m + 15) / 16 + 8;   // (a last step that reaches beyond the matrix takes its pieces from the zeros)
   for (int q = 0; q <= split; ++q) A.gb[q] = (int)((long long)ks_all * q / split);
+  static const int env_hot = [] { const char* e = getenv("SPRINGCRAFT_SYMM3_DBG_HOT"); return e ? atoi(e) : 0; }();
+  A.hot = env_hot;
   hipLaunchKernelGGL(k_symm3, dim3((unsigned)nwg), dim3(1024), kS3Lds, ctx->stream, A);
   if (hipGetLastError() != hipSuccess) return 1;
   ++ctx->cnt_symm3_launches;
@@ -530,6 +576,72 @@ extern "C" int sc_dbg_symm3_host(sc_ctx* ctx, const double* a, const double* v, 
         x[(size_t)z * ev + e] = s;
       }
   }
+  (void)hipFree(base);
+  return rc;
+}
+
+extern "C" int sc_dbg_symm3_stamps(unsigned long long* out4) {
+#ifdef SYMM3_STAMPS
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_symm3_stamps), 32) != hipSuccess) return 5;
+  const unsigned long long z[4] = {0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_symm3_stamps), z, 32) == hipSuccess ? 0 : 5;
+#else
+  (void)out4;
+  return 1;
+#endif
+}
+
+// ---- debug / tuning entry (not part of the public C ABI): `count` matrices of order m on freshly allocated buffers, X = A V
+// timed through k_symm3.  tools/symm3_bench.py
+extern "C" int sc_dbg_symm3_bench(sc_ctx* ctx, int count, int m, int split, int iters, double* ms_out) {
+  if (!ctx || count < 1 || iters < 1 || m < 256) return SC_ERR_INVALID_ARG;
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t ea = (size_t)m * m, ev = (size_t)m * 64;
+  char* base = nullptr;
+  SC_HIP(ctx, hipMalloc((void**)&base, (ea + ev + ev * split) * count * 8 + sizeof(GemmDesc) * (size_t)count + 256));
+  double* da = (double*)base;
+  double* dv = da + ea * count;
+  double* dx = dv + ev * count;
+  GemmDesc* dd = (GemmDesc*)(dx + ev * split * count);
+  int rc = SC_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && rc == SC_OK) rc = sc_set_error(ctx, SC_ERR_HIP, "%s", hipGetErrorString(e)); };
+  {
+    // (random operands: the clock a launch holds depends on what the matrix pipes multiply -- zeros run ~10 % faster)
+    std::vector<double> hv(std::max(ea, ev));
+    unsigned long long sd = 88172645463325252ull;
+    for (auto& x : hv) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; x = (double)((long long)(sd % 2001) - 1000) / 1000.0; }
+    for (int z = 0; z < count; ++z) {
+      fail(hipMemcpy(da + ea * z, hv.data(), ea * 8, hipMemcpyHostToDevice));
+      fail(hipMemcpy(dv + ev * z, hv.data(), ev * 8, hipMemcpyHostToDevice));
+    }
+  }
+  std::vector<GemmDesc> h((size_t)count);
+  for (int z = 0; z < count; ++z) {
+    GemmDesc D{};
+    D.a = da + ea * z; D.b = dv + ev * z; D.c = dx + ev * split * z;
+    D.m = m; D.n = 64; D.k = m; D.ldc = m; D.alpha = 1.0; D.beta = 0.0;
+    D.sa_i = 1; D.sa_k = m; D.sb_k = 1; D.sb_j = m;
+    D.split_stride = (long long)ev;
+    h[(size_t)z] = D;
+  }
+  fail(hipMemcpy(dd, h.data(), sizeof(GemmDesc) * (size_t)count, hipMemcpyHostToDevice));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (rc == SC_OK) {
+    fail(hipEventCreate(&e0));
+    fail(hipEventCreate(&e1));
+    g_symm3_any_size = true;
+    for (int it = 0; it < 2 && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
+    fail(hipEventRecord(e0, ctx->stream));
+    for (int it = 0; it < iters && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
+    fail(hipEventRecord(e1, ctx->stream));
+    g_symm3_any_size = false;
+    fail(hipEventSynchronize(e1));
+    float ms = 0.f;
+    if (rc == SC_OK) fail(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(base);
   return rc;
 }
