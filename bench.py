@@ -99,7 +99,7 @@ def pmc_traffic(kind, n, batch):
     FETCH_SIZE and WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes).  Returned only when the
     passes were collected at exactly this matrix order AND batch; None otherwise (no extrapolation).
     """
-    names = {"bt2": ["r05_bt2_pmc_fetch_write.json", "r03_bt2_pmc_fetch_write.json"], "symv": ["r02_symv_pmc_fetch_size.json", "r01_symv_pmc_fetch_size.json"]}
+    names = {"bt2": ["r06_bt2_pmc_fetch_write.json", "r05_bt2_pmc_fetch_write.json", "r03_bt2_pmc_fetch_write.json"], "symv": ["r02_symv_pmc_fetch_size.json", "r01_symv_pmc_fetch_size.json"]}
     for name in names[kind]:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -410,7 +410,7 @@ def bulge_compulsory_bytes(n):
 
 
 CHASE_COUNTERS = ("chase_launches", "chase_pair_launches", "chase_timeouts", "chase_resumed", "stepwise_chases",
-                  "gemm3_launches", "panel_coop_launches", "panel_coop_timeouts")
+                  "gemm3_launches", "symm3_launches", "panel_coop_launches", "panel_coop_timeouts")
 
 
 def chase_form(before, after):
@@ -452,13 +452,14 @@ def build_rooflines(t, n, B, ncols, form="per_wavefront"):
               "traffic": pmc_traffic("bt2", n, B) if ncols == n else None})
         mfma("band_reduction", "stage 1 (panel QR + SYMM + Gram + W + SYR2K)", 4.0 / 3.0 * n3 * B, t.get("band_reduction_ms"),
              "4/3 n^3 flops per matrix / duration of the whole stage incl. the panel QRs")
-        mfma("syr2k", "k_gemm2 (trailing SYR2K launches)", 2.0 / 3.0 * n3 * B, t.get("syr2k_ms"),
+        mfma("syr2k", "k_gemm2 / k_gemm3 (trailing SYR2K launches)", 2.0 / 3.0 * n3 * B, t.get("syr2k_ms"),
              "trailing SYR2K launches of the band reduction alone: 2/3 n^3 flops per matrix / their duration")
-        mfma("symm", "k_gemm2 (triangular-operand X = A22 V launches)", 2.0 / 3.0 * n3 * B, t.get("symm_ms"),
-             "X = A22 V on the lower-stored A22: 2/3 n^3 flops per matrix / duration of those launches")
-        mfma("bt1_w", "k_gemm2 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"),
+        mfma("symm", "k_symm3 (X = A22 V, one launch per panel; the last panels and odd orders: k_gemm2 triangular-operand launches)",
+             2.0 / 3.0 * n3 * B, t.get("symm_ms"),
+             "X = A22 V on the lower-stored A22: 2/3 n^3 flops per matrix / duration of those launches (incl. the pair corrections of X)")
+        mfma("bt1_w", "k_gemm3 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"),
              "stage-1 back-transformation, first product: n^2 ncols flops per matrix")
-        mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
+        mfma("bt1_update", "k_gemm3 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
              "stage-1 back-transformation, second product: n^2 ncols flops per matrix")
         if t.get("dc_gemm_gflop", 0) > 0:
             mfma("dc_gemm", "k_gemm2 (D&C merge products, gathered operands)", t["dc_gemm_gflop"] * 1e9, t.get("dc_gemm_ms"),
@@ -502,8 +503,8 @@ def build_rooflines(t, n, B, ncols, form="per_wavefront"):
         if t.get("dc_gemm_gflop", 0) > 0:
             mfma("dc_gemm", "k_gemm2 (D&C merge products, gathered operands)", t["dc_gemm_gflop"] * 1e9, t.get("dc_gemm_ms"),
                  "eigenvector updates of the divide & conquer merges: 2 m n k per merge record, summed on the device")
-        mfma("bt1_w", "k_gemm2 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"), "back-transformation, first product")
-        mfma("bt1_update", "k_gemm2 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
+        mfma("bt1_w", "k_gemm3 (W = V^T Z)", float(n) * n * ncols * B, t.get("bt1_w_ms"), "back-transformation, first product")
+        mfma("bt1_update", "k_gemm3 (Z -= (V T) W)", float(n) * n * ncols * B, t.get("bt1_update_ms"),
              "back-transformation, second product")
     # dominant = the single kernel (group) with the longest duration; the band reduction as a whole is a stage, not a kernel
     kernels = {k: v for k, v in cand.items() if k != "band_reduction"}

@@ -477,3 +477,46 @@ def test_device_solve_only_enqueues_at_n6000():
         assert np.abs(w[0].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,batch,want_symm3", [(2049, 16, False), (2000, 4, True), (3000, 6, True)])
+def test_symm_k_slices_in_a_batched_solve(n, batch, want_symm3):
+    """
+    The band reduction's X = A22 V with K slices, inside batched solves: 16 x n = 2049 has 528
+    64-row tiles -- the regime in which the triangular-operand launches take FIVE slices (an odd order keeps k_symm3 out);
+    4 x n = 2000 and 6 x n = 3000 (no multiple of 16) run k_symm3 with 16 resp. 11 slices per tile.  Every member:
+    residual and orthogonality; eigenvalues of the first and last against LAPACK.
+    """
+    import ctypes as C
+    import os
+
+    import torch
+
+    from springcraft_amd import _hip
+
+    if os.environ.get("SPRINGCRAFT_SYMM_SPLIT") or os.environ.get("SPRINGCRAFT_SYMM3") == "0":
+        pytest.skip("the slice rule / the kernel choice is overridden (tools/test_matrix.sh)")
+    L = _hip.lib()
+    rs = np.random.RandomState(n + batch)
+    mats = np.stack([sym(rs, n) for _ in range(batch)])
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_two_stage(True)
+        a = torch.from_numpy(mats.copy()).cuda()
+        w = torch.empty((batch, n), dtype=torch.float64, device="cuda")
+        v = torch.empty((batch, n, n), dtype=torch.float64, device="cuda")
+        ctx.check(L.sc_dev_eigh_f64(ctx.handle, C.c_void_p(a.data_ptr()), n, batch, C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(v.data_ptr())))
+        ctx.synchronize()
+        assert (ctx.counter("symm3_launches") > 0) == want_symm3
+        am = torch.from_numpy(mats).cuda()
+        eye = torch.eye(n, dtype=torch.float64, device="cuda")
+        for b in range(batch):
+            r = am[b] @ v[b].T - v[b].T * w[b][None, :]
+            assert float(r.abs().max()) <= 1e-10 * float(w[b].abs().max()), b
+            assert float((v[b] @ v[b].T - eye).abs().max()) <= 1e-11, b
+        for b in sorted({0, batch - 1}):
+            w_ref = np.linalg.eigvalsh(mats[b])
+            assert np.abs(w[b].cpu().numpy() - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    finally:
+        ctx.close()

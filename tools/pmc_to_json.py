@@ -35,7 +35,7 @@ z_bytes = 8 * n * sum(min(n, 64 * g + 1 + 64 * ((n - 1 - 64 * g + 63) // 64) + 6
 frag_bytes = ndia * 4 * 40 * 64 * 8
 alg = batch * (2 * z_bytes + frag_bytes)
 out = {
-    "command": "bash tools/r05_final.sh b  ->  bash tools/pmc_kernel.sh %s <tag>  (rocprofv3 --pmc, counters only, separate passes: "
+    "command": "bash tools/r06_final.sh b  ->  bash tools/pmc_kernel.sh %s <tag>  (rocprofv3 --pmc, counters only, separate passes: "
                "SQ counters | FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; --kernel-trace --kernel-include-regex; "
                "python3 bench.py --no-cpu-baseline --steps 1 --warmup 0), summed by tools/pmc_to_json.py" % kernel,
     "kernel": kernel, "n": n, "batch": batch,

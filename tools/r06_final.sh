@@ -1,0 +1,79 @@
+#!/bin/bash
+# Round-6 evidence on one GPU box, in parts (a gpurun call is limited to 20 minutes):
+#   bash tools/r06_final.sh a   the -m gpu suite with durations, the four bench lines (C3 with the CPU baseline), latencies
+#   bash tools/r06_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
+#                               runs) of k_bt2_apply (bytes, MFMA-pipe occupancy at the benchmarked batch), of k_symm3 and
+#                               of k_bulge_pair (bytes)
+#   bash tools/r06_final.sh c1 | c2 | c3 | c4   the test matrix (tools/test_matrix.sh), in four parts
+#   bash tools/r06_final.sh d   k_bulge_pair: per-phase stamps without / with loader waves and with the early look, the
+#                               diagnostic variants (512-thread form under the 768-thread form's register budget; loader
+#                               waves that request nothing), same-box A/B of the three forms on the bench step
+#   bash tools/r06_final.sh e   k_symm3: micro-bench (random and zero-like "hot" operands), loader-wave stamps, on / off in
+#                               the bench step and in C5 / C4 / C2; trailing update on 224 / 256 workgroups; D&C per level
+#   bash tools/r06_final.sh f   two-rank rehearsal on the shared GPU (bench.py --gpus 2, gloo)
+# Everything lands in gpurun_out/r06_final/; what is to be judged is copied to profiles/r06_* (tools/r06_collect.sh).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r06_final
+mkdir -p $OUT
+cd $ROOT
+part=${1:-a}
+if [ $part = a ]; then
+  timeout -k 10 900 python -m pytest tests -m gpu -q --durations=15 > $OUT/gputest_durations.txt 2>&1 || { tail -30 $OUT/gputest_durations.txt; exit 1; }
+  tail -3 $OUT/gputest_durations.txt
+  timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+  python tools/show_bench.py $OUT/bench.json
+  for c in c2 c4 c5; do
+    timeout -k 10 300 python bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err || { tail -5 $OUT/bench_$c.err; exit 1; }
+    python tools/show_bench.py $OUT/bench_$c.json
+  done
+  timeout -k 10 300 python tools/latency_phases.py > $OUT/latency.txt 2>&1 || exit 1
+  grep -v amdgpu.ids $OUT/latency.txt
+elif [ $part = b ]; then
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench --output-format csv -- \
+     python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err) || { tail -5 $OUT/bench_under_rocprof.err; exit 1; }
+  rm -f $OUT/prof/*kernel_trace.csv $OUT/prof/*/*kernel_trace.csv
+  cp $(ls $OUT/prof/*kernel_stats.csv $OUT/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_bench.csv
+  head -8 $OUT/rocprofv3_kernel_stats_bench.csv | cut -c1-200
+  bash tools/pmc_kernel.sh k_bt2_apply r06_bt2 || exit 1
+  bash tools/pmc_mfma.sh k_bt2_apply r06_bt2 > $OUT/bt2_pmc_mfma.txt 2>&1 || exit 1
+  python3 tools/pmc_to_json.py gpurun_out/pmc_r06_bt2 k_bt2_apply 6000 64 > $OUT/bt2_pmc_fetch_write.json
+  grep -E "traffic_over|l2_hit|hbm_bytes" $OUT/bt2_pmc_fetch_write.json
+  python3 tools/pmc_summary.py gpurun_out/pmc_r06_bt2 > $OUT/bt2_pmc_summary.txt 2>&1
+  bash tools/pmc_kernel.sh k_symm3 r06_symm3 > /dev/null 2>&1 || exit 1
+  bash tools/pmc_mfma.sh "k_symm3|k_gemm3" r06_symm3 > $OUT/symm3_pmc_mfma.txt 2>&1 || exit 1
+  python3 tools/pmc_summary.py gpurun_out/pmc_r06_symm3 | cut -c1-700 > $OUT/symm3_pmc_summary.txt 2>&1
+  cat $OUT/symm3_pmc_summary.txt | cut -c1-300
+  bash tools/pmc_kernel.sh k_bulge_pair r06_bulge > /dev/null 2>&1 || exit 1
+  python3 tools/pmc_to_json.py gpurun_out/pmc_r06_bulge k_bulge_pair 6000 64 > $OUT/bulge_pmc_fetch_write.json
+  grep -E "traffic_over|l2_hit|hbm_bytes" $OUT/bulge_pmc_fetch_write.json
+elif [ $part = c1 ] || [ $part = c2 ] || [ $part = c3 ] || [ $part = c4 ]; then
+  k=${part#c}
+  bash tools/test_matrix.sh $k 4 > $OUT/test_matrix_$k.txt 2>&1
+  cat $OUT/test_matrix_$k.txt
+elif [ $part = d ]; then
+  bash tools/r06_pair_stamps.sh > $OUT/pair_stamps.txt 2>&1
+  { echo "== early look (SPRINGCRAFT_PAIR_EARLY=1), no loader waves";
+    SPRINGCRAFT_PAIR_EARLY=1 SPRINGCRAFT_HIP_LIB=$PWD/springcraft_amd/libspringcraft_hip_stamps.so timeout -k 10 300 python tools/pair_stamps.py 2000 64 2>/dev/null; } >> $OUT/pair_stamps.txt
+  bash tools/r06_pair_variants.sh >> $OUT/pair_stamps.txt 2>&1
+  grep -v "^rc 0$" $OUT/pair_stamps.txt
+  bash tools/quick_env_ab.sh "SPRINGCRAFT_PAIR_LOADER=0" "SPRINGCRAFT_PAIR_LOADER=1" "SPRINGCRAFT_PAIR_EARLY=1" > $OUT/pair_ab.txt 2>&1
+  cat $OUT/pair_ab.txt
+elif [ $part = e ]; then
+  { python tools/symm3_bench.py; SPRINGCRAFT_SYMM3_DBG_HOT=1 python tools/symm3_bench.py 32 5888 1 64 3008 1; } 2>/dev/null > $OUT/symm3_bench.txt
+  cat $OUT/symm3_bench.txt
+  bash tools/r06_symm3_stamps.sh > $OUT/symm3_stamps.txt 2>&1; SPRINGCRAFT_SYMM3_DBG_HOT=1 bash tools/r06_symm3_stamps.sh >> $OUT/symm3_stamps.txt 2>&1
+  cat $OUT/symm3_stamps.txt
+  bash tools/quick_env_ab.sh "SPRINGCRAFT_SYMM3=0 SPRINGCRAFT_GEMM3_LOWER=0" "SPRINGCRAFT_SYMM3=0" "SPRINGCRAFT_GEMM3_LOWER=0" "X=default" "SPRINGCRAFT_SYMM3_WGS=256 SPRINGCRAFT_GEMM3_LOWER_WGS=256" > $OUT/symm3_syr2k_ab.txt 2>&1
+  cat $OUT/symm3_syr2k_ab.txt
+  ENVS="SPRINGCRAFT_SYMM3=0;SPRINGCRAFT_SYMM3=1" bash tools/r06_cfgs.sh > $OUT/symm3_cfgs.txt 2>&1
+  grep -v "^    {" $OUT/symm3_cfgs.txt
+  bash tools/r06_dc_levels.sh > $OUT/dc_levels.txt 2>&1
+  cat $OUT/dc_levels.txt
+else
+  SPRINGCRAFT_BENCH_SHARE_GPUS=1 timeout -k 10 500 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/rehearsal_2ranks.json 2> $OUT/rehearsal_2ranks.err; echo "rehearsal rc $?"
+  python tools/show_bench.py $OUT/rehearsal_2ranks.json
+  SPRINGCRAFT_BENCH_SHARE_GPUS=1 timeout -k 10 400 python bench.py --gpus 2 --config c4 --steps 2 --warmup 1 > $OUT/rehearsal_c4_2ranks.json 2> $OUT/rehearsal_c4_2ranks.err; echo "rehearsal c4 rc $?"
+  python tools/show_bench.py $OUT/rehearsal_c4_2ranks.json
+fi
+echo "part $part done"
