@@ -87,7 +87,7 @@ int sc_dbg_bulge_stamps(unsigned long long* out6);
 /* The same for the pair form of the persistent chase (k_bulge_pair; library built with -DPAIR_STAMPS, else returns 1):
  * 48 entries.  [0..15] thread 0 (team A): [0..6] = cycles between the barriers of a common step (wait + [0], block reads +
  * [1], E right update + reflector, column sums + D image, E left update + D products, w, D update), [8] = steps, [9] =
- * common steps, [12] = block reads alone; [16..31] thread 256 (team B), same layout, [26] slot reads, [27] store drain,
+ * common steps, [12] = block reads alone; [16..31] thread 256 (team B), same layout, [23] its look at the predecessor pair, [30] steps in which it polled, [26] slot reads, [27] store drain,
  * [29] D update + stores; [32..47] lane 0 of the first loader wave (k_bulge_pair<1>): [32] wait for E, [33] barrier [0],
  * [34] [1] [2], [35] wait for D, [36] [3] [4], [37] E requests, [38] [5] [6] [7], [39] D requests, [40] steps counted. */
 int sc_dbg_pair_stamps(unsigned long long* out48);

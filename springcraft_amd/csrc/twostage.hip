@@ -2708,7 +2708,7 @@ __global__ __launch_bounds__(PAIR_BOUNDS(LOADER), 1) void k_bulge_pair(double* _
         }
         if (go && (have_c < need || (!prev && (m & 7) == 0))) {
 #ifdef PAIR_STAMPS
-          s_pair_stamps[16 + 10] += 1ull;
+          s_pair_stamps[16 + 14] += 1ull;
 #endif
           const int want = prev ? min(need + 1, len_prev) : need;
           const int stop0 = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

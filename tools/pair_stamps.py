@@ -46,8 +46,8 @@ for k, name in enumerate(names):
 print(f"  {'step':72s} {tot[0] / steps:12.0f} {tot[1] / steps:14.0f}")
 print(f"  inside [1]: team A, block reads issued + vp read {v[12] / steps:.0f}; team B: slot reads {v[26] / steps:.0f}, "
       f"store drain {v[27] / steps:.0f} cycles")
-print(f"  thread 0 inside [0]: {v[7] / steps:.0f} cycles in the block that reads the predecessor's counter, which it does in "
-      f"{v[10] / max(1, v[8]):.2f} of the steps")
+print(f"  thread 256 inside [0]: {v[16 + 7] / steps:.0f} cycles in the block that looks at the predecessor pair's counter; it polls in "
+      f"{v[16 + 14] / max(1, v[8]):.2f} of the steps (early look: {os.environ.get('SPRINGCRAFT_PAIR_EARLY', '0')})")
 if v[40]:
     ls = v[40]
     ln = ["wait for this step's E pieces", "barrier [0]", "barriers [1] [2]", "wait for this step's D pieces", "barriers [3] [4]",

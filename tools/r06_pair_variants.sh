@@ -5,12 +5,12 @@ cd ${GRAFT_REPO_ROOT:-.}
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 if [ "$1" = build ]; then
   python springcraft_amd/csrc/build.py > /dev/null
-  for var in POLL32; do
+  for var in CAP168 NODMA; do
     $HIPCC -c springcraft_amd/csrc/twostage.hip -o /tmp/twostage_$var.o --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall \
       -Wno-unused-function -I include -mllvm -pragma-unroll-threshold=1000000 -DPAIR_STAMPS -DPAIR_VAR_$var &
   done
   wait
-  for var in POLL32; do
+  for var in CAP168 NODMA; do
     $HIPCC -shared -fPIC --offload-arch=gfx950 -o springcraft_amd/libspringcraft_hip_var_$var.so /tmp/twostage_$var.o \
       $(ls springcraft_amd/csrc/obj/*.o | grep -v twostage.o)
   done
@@ -25,5 +25,3 @@ if [ -f springcraft_amd/libspringcraft_hip_var_CAP168.so ]; then
 echo "== 512-thread form compiled for 168 registers"; run libspringcraft_hip_var_CAP168.so 0
 echo "== loader waves present, nothing requested (results wrong by construction)"; run libspringcraft_hip_var_NODMA.so 1
 fi
-echo "== stamps build, no loader"; run libspringcraft_hip_stamps.so 0
-echo "== stop flag / counter read every 32nd step instead of every 8th"; run libspringcraft_hip_var_POLL32.so 0
