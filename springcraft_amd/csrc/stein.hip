@@ -162,8 +162,13 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
     return (int)cnt;
   };
   double a = lo, b = hi;   // invariant: count_below(a) <= k < count_below(b)
+  // Stop at a bracket of eps |T| (dstebz's abstol): narrower brackets cost counts and, next to an exactly
+  // zero eigenvalue of a decoupled block, drive the shift into the range where the product-form count flushes rows to
+  // sign changes (tools/models/sturm_product_model.py) -- the value returned is the same to eps |T| either way
+  const double tol = 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi));
   for (int round = 0; round < 16; ++round) {
     const double width = b - a;
+    if (width <= tol) break;
     const double x = a + width * ((double)(lane + 1) / 65.0);
     if (__any(!(x > a && x < b))) break;      // the bracket is down to a few numbers (decided for the whole wave)
     const int cnt = count_below(x);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64) void k_sturm_range(const double* __restrict__ t
   }
   for (int it = 0; it < 120; ++it) {
     const double mid = 0.5 * (a + b);
-    if (mid <= a || mid >= b) break;
+    if (mid <= a || mid >= b || b - a <= tol) break;
     if (count_below(mid) > k) b = mid; else a = mid;
   }
   if (lane == 0) w_all[(size_t)blockIdx.y * stride_w + j] = 0.5 * (a + b);

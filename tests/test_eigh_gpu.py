@@ -277,6 +277,31 @@ def test_partial_spectrum_exactly_degenerate(sc):
     assert np.allclose(w, 3.0) and np.abs(v @ v.T - np.eye(20)).max() <= 1e-10
 
 
+def test_partial_spectrum_exact_zero_block(sc):
+    """
+    ADVICE round 5: a matrix with a decoupled block of exactly zero eigenvalues (a tridiagonal matrix with exact zeros
+    on its diagonal and sub-diagonal there): the Sturm bisection stops at a bracket of eps |T| instead of driving its
+    shifts into the range where the product-form count flushes rows; the zero eigenvalues come back as |w| <= eps |T|
+    with orthonormal vectors, the others as LAPACK's.
+    """
+    n = 96
+    rs = np.random.RandomState(4)
+    d = rs.uniform(1.0, 3.0, n)
+    e = rs.uniform(0.2, 0.5, n - 1)
+    d[40:52] = 0.0                                   # twelve exactly zero rows ...
+    e[39:52] = 0.0                                   # ... decoupled from both neighbours
+    a = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    w_ref = np.linalg.eigvalsh(a)
+    k0 = int(np.sum(w_ref < -1e-12))                 # eigenvalues below the zero cluster
+    lo, hi = max(0, k0 - 3), min(n - 1, k0 + 12 + 3)
+    w, v = sc.nma.eigh(a, subset_by_index=(lo, hi))
+    scale = np.abs(w_ref).max()
+    assert np.abs(w - w_ref[lo:hi + 1]).max() <= 1e-13 * scale
+    assert np.sum(np.abs(w) <= 4e-16 * scale) == 12
+    assert np.abs(v @ v.T - np.eye(hi - lo + 1)).max() <= 1e-10
+    assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-12 * scale
+
+
 def test_config5_anm_n8000_lowest_modes(sc):
     """Config 5: N = 8000 C-alpha (24000 x 24000 Hessian), InvariantForceField 13 A, modes 0..105."""
     import os

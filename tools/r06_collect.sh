@@ -1,0 +1,54 @@
+#!/bin/bash
+# gpurun_out/r06_final/* (written by tools/r06_final.sh on the GPU box)  ->  profiles/r06_*
+set -eu
+cd $(dirname $0)/..
+F=gpurun_out/r06_final
+P=profiles
+line() { grep '^{' $1 | tail -1; }
+line $F/bench.json > $P/r06_bench.json
+for c in c2 c4 c5; do line $F/bench_$c.json > $P/r06_bench_$c.json; done
+grep -v amdgpu.ids $F/latency.txt > $P/r06_latency.txt
+cp $F/gputest_durations.txt $P/r06_gputest_durations.txt
+cp $F/rocprofv3_kernel_stats_bench.csv $P/r06_rocprofv3_kernel_stats_bench.csv
+cp $F/bt2_pmc_fetch_write.json $P/r06_bt2_pmc_fetch_write.json
+cp $F/bt2_pmc_summary.txt $P/r06_bt2_pmc_summary.txt
+grep -h "^run_mfma" $F/bt2_pmc_mfma.txt > $P/r06_bt2_pmc_mfma.txt
+{ echo "# tools/pmc_kernel.sh k_symm3 + tools/pmc_mfma.sh 'k_symm3|k_gemm3' on the default bench step (counters only, separate passes)."
+  echo "# FETCH_SIZE is in KiB and counts 128-byte requests as 64 bytes on gfx950: read bytes = 2 x FETCH_SIZE x 1024 (per dispatch mean)."
+  echo "# MFMA pipes busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."
+  cat $F/symm3_pmc_summary.txt; grep -h "^run_mfma" $F/symm3_pmc_mfma.txt | cut -c1-400; } > $P/r06_symm3_pmc.txt
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+d = json.load(open("gpurun_out/r06_final/bulge_pmc_fetch_write.json"))
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", "bench.py"); b = importlib.util.module_from_spec(spec)
+try:
+    spec.loader.exec_module(b)
+    task = b.bulge_bytes(6000) * 64 / 2.0   # the pair form moves half the bytes the tasks touch
+except Exception as e:
+    task = None
+out = {"kernel": "k_bulge_pair<0> (unchanged since round 4)", "n": 6000, "batch": 64,
+       "command": d.get("command"), "counters_per_launch_mean": d.get("counters_per_launch_mean"),
+       "units_and_corrections": d.get("units_and_corrections"),
+       "hbm_read_bytes_per_launch_corrected": d.get("hbm_read_bytes_per_launch_corrected"),
+       "hbm_write_bytes_per_launch": d.get("hbm_write_bytes_per_launch"),
+       "hbm_bytes_per_launch_corrected": d.get("hbm_bytes_per_launch_corrected"), "l2_hit_rate": d.get("l2_hit_rate"),
+       "task_bytes_per_launch": task,
+       "traffic_over_task_bytes": (d["hbm_bytes_per_launch_corrected"] / task) if task else None}
+json.dump(out, open("profiles/r06_bulge_pmc_fetch_write.json", "w"), indent=1)
+print("bulge traffic / task bytes:", out["traffic_over_task_bytes"])
+PY
+cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt $F/test_matrix_4.txt | grep -v "^part" > $P/r06_test_matrix.txt
+grep -v "^rc 0$" $F/pair_stamps.txt | grep -v amdgpu.ids > $P/r06_pair_stamps.txt
+cp $F/pair_ab.txt $P/r06_pair_ab.txt
+{ echo "== tools/symm3_bench.py (k_symm3 alone, random operands; last two lines: every column of A redirected to one hot column)"; cat $F/symm3_bench.txt
+  echo; echo "== tools/r06_symm3_stamps.sh (first loader wave of every workgroup, one C3 step; second line: hot column)"; grep "^rc" $F/symm3_stamps.txt
+  echo; echo "== tools/quick_env_ab.sh on the bench step: k_symm3 / the trailing update on k_gemm3, on and off"; cat $F/symm3_syr2k_ab.txt
+  echo; echo "== tools/r06_cfgs.sh: the other configurations with SPRINGCRAFT_SYMM3 = 0 / 1"; grep -v "^    {" $F/symm3_cfgs.txt; } > $P/r06_symm3.txt
+cp $F/syr2k_wgs.txt $P/r06_syr2k_wgs.txt
+cp $F/dc_levels.txt $P/r06_dc_levels.txt
+cp $F/probe_i8_emulation.txt $P/r06_probe_i8_emulation.txt
+line $F/rehearsal_2ranks.json > $P/r06_rehearsal_2ranks.json
+line $F/rehearsal_c4_2ranks.json > $P/r06_rehearsal_c4_2ranks.json
+ls -la $P/r06_* | awk '{print $5, $9}'

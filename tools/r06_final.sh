@@ -66,10 +66,13 @@ elif [ $part = e ]; then
   cat $OUT/symm3_stamps.txt
   bash tools/quick_env_ab.sh "SPRINGCRAFT_SYMM3=0 SPRINGCRAFT_GEMM3_LOWER=0" "SPRINGCRAFT_SYMM3=0" "SPRINGCRAFT_GEMM3_LOWER=0" "X=default" "SPRINGCRAFT_SYMM3_WGS=256 SPRINGCRAFT_GEMM3_LOWER_WGS=256" > $OUT/symm3_syr2k_ab.txt 2>&1
   cat $OUT/symm3_syr2k_ab.txt
+  bash tools/quick_env_ab.sh "SPRINGCRAFT_SYMM3_WGS=208 SPRINGCRAFT_GEMM3_LOWER_WGS=208" "SPRINGCRAFT_SYMM3_WGS=216 SPRINGCRAFT_GEMM3_LOWER_WGS=216" "X=default224" "SPRINGCRAFT_SYMM3_WGS=240 SPRINGCRAFT_GEMM3_LOWER_WGS=240" "SPRINGCRAFT_STAGE1_STREAMS=3" > $OUT/syr2k_wgs.txt 2>&1
+  cat $OUT/syr2k_wgs.txt
   ENVS="SPRINGCRAFT_SYMM3=0;SPRINGCRAFT_SYMM3=1" bash tools/r06_cfgs.sh > $OUT/symm3_cfgs.txt 2>&1
   grep -v "^    {" $OUT/symm3_cfgs.txt
   bash tools/r06_dc_levels.sh > $OUT/dc_levels.txt 2>&1
   cat $OUT/dc_levels.txt
+  bash tools/r06_probe_i8.sh > /dev/null 2>&1; cp gpurun_out/r06/probe_i8_emulation.txt $OUT/probe_i8_emulation.txt; tail -12 $OUT/probe_i8_emulation.txt
 else
   SPRINGCRAFT_BENCH_SHARE_GPUS=1 timeout -k 10 500 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/rehearsal_2ranks.json 2> $OUT/rehearsal_2ranks.err; echo "rehearsal rc $?"
   python tools/show_bench.py $OUT/rehearsal_2ranks.json
