@@ -287,14 +287,16 @@ int sc_last_eigh_timings(sc_ctx* ctx, double* out6);
  * Unknown names (or phases the last solve did not run): SC_ERR_INVALID_ARG, *ms = 0. */
 int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
 
-/* Event counters of the context since it was created (monitoring; nothing in the reference corresponds).  Names:
+/* Event counters of the context since it was created (monitoring; nothing in the reference corresponds).  Since round 6
+ * the persistent kernels' outcomes are collected on the device while solves are being enqueued; this call waits for the
+ * context's stream and reads them (as sc_ctx_synchronize does).  Names:
  *   "chase_launches"   persistent bulge chases started (two-stage path): one launch for the whole stage
  *   "chase_pair_launches"   of those, how many ran in the pair form (two sweeps per workgroup through LDS, the form for
  *                      batches that are bound by memory traffic; smaller ones take one sweep per workgroup)
  *   "chase_timeouts"   of those, how many ran into the bound of an inter-workgroup wait -- expected to stay 0; the
- *                      solve is still finished correctly by the per-wavefront launches ("chase_resumed" counts every
- *                      such take-over, "chase_incomplete" a chase that ended without a flag but with sweeps left),
- *                      and the context stops using the persistent form
+ *                      solve is still finished correctly, on the device, by the take-over launch behind the chase
+ *                      ("chase_resumed" counts every such take-over, "chase_incomplete" a chase that ended without a
+ *                      flag but with sweeps left), and the context stops using the persistent form
  *   "chase_sweeps"     sweeps the persistent chases finished themselves
  *   "stepwise_chases"  bulge chases that ran as per-wavefront launches from the start
  *   "chase_xcd_min" / "chase_xcd_max"   workgroups per XCD in the most recent persistent chase
@@ -302,9 +304,12 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
  *   "chase_pair_fallbacks"   pair launches the device refused (dynamic LDS) and that were re-issued in the one-sweep form
  *   "xcd_count"        XCDs of the device as a probe launch saw them (0: not probed yet)
  *   "gemm3_launches"   launches the role-split persistent GEMM (k_gemm3) took
+ *   "symm3_launches"   launches of the band reduction's symmetric product X = A22 V as one role-split kernel (k_symm3)
  *   "panel_coop_launches"   panel factorisations by the cooperative kernel (k_panel_coop: several workgroups of one launch)
- *   "panel_coop_timeouts"   of those, how many ran into the bound of a wait between its workgroups -- expected to stay 0;
- *                      the solve returns SC_ERR_NOCONV and the context keeps to the chunked panel launches afterwards
+ *   "panel_coop_timeouts"   panels (per matrix) the cooperative kernel gave up on -- a wait between its workgroups ran
+ *                      into its bound; expected to stay 0 -- and the take-over launch behind it factored instead: the
+ *                      solve is correct, the context keeps to the chunked panel launches afterwards (until round 5 the
+ *                      solve returned SC_ERR_NOCONV)
  * Unknown names: SC_ERR_INVALID_ARG, *value = 0. */
 int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value);
 

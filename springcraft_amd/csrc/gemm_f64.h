@@ -67,5 +67,6 @@ bool gemm3_would_take(sc_ctx* ctx, int count, int m, int n, int k, int layout, i
 // SC_OK when it took the launch, 1 when the launch is not one it takes (m a multiple of 16, 16-byte aligned operands,
 // enough tiles; SPRINGCRAFT_SYMM3 = 0 switches it off, = 2 takes every launch that qualifies).  split: K slices, slice s
 // into c + s * split_stride.  The kernel reads A where (row | 1) >= col: see its header for what the writers of A keep.
-int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int split, bool aligned16);
+// any_size: skip the "enough work items" part of the decision (the caller made it for another record count).
+int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int split, bool aligned16, bool any_size = false);
 bool symm3_would_take(sc_ctx* ctx, int count, int m, int split, bool aligned16);

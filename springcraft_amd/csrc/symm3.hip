@@ -499,21 +499,26 @@ bool g_symm3_any_size = false;   // debugging (sc_dbg_symm3_host): take every la
 }
 
 // Whether launch_symm3 takes X = A V for `count` symmetric matrices of order m with `split` K slices (see the header).
-bool symm3_would_take(sc_ctx* ctx, int count, int m, int split, bool aligned16) {
+static bool symm3_takes(sc_ctx* ctx, int count, int m, int split, bool aligned16, bool any_size) {
   static const int env = [] { const char* e = getenv("SPRINGCRAFT_SYMM3"); return e ? atoi(e) : 1; }();
   if (env == 0 || count <= 0 || !aligned16) return false;
   if (m < 256 || (m & 1)) return false;
   if (split < 1 || split > 16 || ((m + 15) / 16 + 8) / split < 4) return false;   // (every item has a few K steps)
   if (ctx->num_cus < 256) return false;   // (the item order is built on 8 XCDs x 32 workgroups)
   const long long items = (long long)((m + 127) / 128) * split * count;
-  if (env != 2 && !g_symm3_any_size && items < 256) return false;
+  if (env != 2 && !any_size && items < 256) return false;
   return items <= 0x3fffffffLL;
 }
 
 // X = A V on k_symm3 (records: a = A(0, 0), sa_i = 1, sa_k = lda; b = V, sb_k = 1, sb_j = ldb; c = X, ldc; split_stride);
 // returns SC_OK when the launch went out, 1 when it is not one the kernel takes.
-int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int split, bool aligned16) {
-  if (!symm3_would_take(ctx, count, m, split, aligned16)) return 1;
+bool symm3_would_take(sc_ctx* ctx, int count, int m, int split, bool aligned16) {
+  return symm3_takes(ctx, count, m, split, aligned16, g_symm3_any_size);
+}
+
+int launch_symm3(sc_ctx* ctx, const GemmDesc* d_desc, int count, int m, int split, bool aligned16, bool any_size) {
+  // (any_size: the caller has decided with symm3_would_take for another record count -- the parts of a split batch)
+  if (!symm3_takes(ctx, count, m, split, aligned16, any_size || g_symm3_any_size)) return 1;
   if (!sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_symm3), kS3Lds)) return 1;
   if (!ctx->d_zeros) return 1;   // (16 KB of zeros, allocated with the context; the kernel is handed its middle)
   // (workgroups: one per CU, or 224 while the caller runs parts of the batch on several streams -- the other part's panel
@@ -560,7 +565,7 @@ extern "C" int sc_dbg_symm3_host(sc_ctx* ctx, const double* a, const double* v, 
   fail(hipMemcpy(dd, h.data(), sizeof(GemmDesc) * (size_t)count, hipMemcpyHostToDevice));
   if (rc == SC_OK) {
     g_symm3_any_size = true;
-    const int took = launch_symm3(ctx, dd, count, m, split, true);
+    const int took = launch_symm3(ctx, dd, count, m, split, true, true);
     g_symm3_any_size = false;
     if (took != SC_OK) rc = sc_set_error(ctx, SC_ERR_INVALID_ARG, "k_symm3 does not take m %d split %d", m, split);
     fail(hipStreamSynchronize(ctx->stream));
@@ -630,9 +635,9 @@ extern "C" int sc_dbg_symm3_bench(sc_ctx* ctx, int count, int m, int split, int 
     fail(hipEventCreate(&e0));
     fail(hipEventCreate(&e1));
     g_symm3_any_size = true;
-    for (int it = 0; it < 2 && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
+    for (int it = 0; it < 2 && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
     fail(hipEventRecord(e0, ctx->stream));
-    for (int it = 0; it < iters && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
+    for (int it = 0; it < iters && rc == SC_OK; ++it) rc = launch_symm3(ctx, dd, count, m, split, true, true) == SC_OK ? SC_OK : SC_ERR_INVALID_ARG;
     fail(hipEventRecord(e1, ctx->stream));
     g_symm3_any_size = false;
     fail(hipEventSynchronize(e1));

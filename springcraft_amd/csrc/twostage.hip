@@ -4290,6 +4290,11 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
   // k_symm3 writes X into the X1 block of [X1 | X2 | V]; the X2 block reads zero for the whole solve (the panels at the
   // end of the reduction that fall back to the two triangular-operand launches rewrite their rows of it themselves)
   const bool use_symm3 = symm3_for(n) && (n & 1) == 0;
+  // (whether a panel takes it is decided for the SMALLEST part of a batch that is split over streams, and then holds for
+  // every part: the same structure at two batch positions must not meet two kernels -- other summation orders, other last
+  // bits; found by tools/test_matrix.sh with three parts of unequal size, profiles/r06_test_matrix.txt)
+  const int symm3_parts = std::max(1, std::min(env_s1_early > 0 ? env_s1_early : ((batch >= 32 && !prof) ? 2 : 1), std::min(batch, 4)));
+  const int symm3_nb_min = std::max(1, batch / symm3_parts);
   if (use_symm3)
     for (int b = 0; b < batch; ++b)
       SC_HIP(ctx, hipMemsetAsync(d_sb_ws + (size_t)b * SL.slab + SL.xv + (size_t)kB * n, 0, sizeof(double) * (size_t)kB * n, st));
@@ -4372,7 +4377,8 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     if (timed) t_symm.start();
     // X = A22 V: one launch of k_symm3 (X into X1; X2 was zeroed for the whole solve) while the panel has enough tiles
     // for it, else X1 = L V and X2 = strict(L)^T V by two triangular-operand launches of k_gemm2
-    if (use_symm3 && launch_symm3(ctx, g + lo, nb, m, SL.symm_split, /*aligned16=*/true) == SC_OK) {
+    if (use_symm3 && symm3_would_take(ctx, symm3_nb_min, m, SL.symm_split, /*aligned16=*/true) &&
+        launch_symm3(ctx, g + lo, nb, m, SL.symm_split, /*aligned16=*/true, /*any_size=*/true) == SC_OK) {
       if (SL.symm_split > 1)
         hipLaunchKernelGGL(k_sum_xslices, dim3((unsigned)((m + 255) / 256), kB, (unsigned)nb), dim3(256), 0, ps, sb_h, SL, r0);
     } else {
