@@ -98,9 +98,10 @@ int sc_dbg_chase_stamps(unsigned long long* out16);
 
 /* Persistent bulge chase of this context: mode -1 = SPRINGCRAFT_BULGE_PERSISTENT or the size rule (default), 0 never,
  * 1 by size, 2 always (3: always and in the pair form k_bulge_pair, 4: always with one sweep per workgroup,
- * k_bulge_chase; 2 picks the form by size like the default).  give_up_after > 0: test hook, every workgroup of the chase raises the time-out flag after that
- * many tasks, which forces the take-over by the per-wavefront launches (counted in "chase_resumed", not in
- * "chase_timeouts").  tests/test_two_stage_gpu.py */
+ * k_bulge_chase, a matrix on one XCD; 5: as 4 with the workgroups of a matrix on all XCDs -- fewer matrices than XCDs only;
+ * 2 picks the form by size like the default).  give_up_after > 0: test hook, every workgroup of the chase raises the
+ * time-out flag after that many tasks, which forces the take-over on the device (k_chase_finish; counted in
+ * "chase_resumed", not in "chase_timeouts").  tests/test_two_stage_gpu.py */
 int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after);
 
 /* Cooperative panel QR of this context (k_panel_coop: several workgroups of one launch own 256 rows of a panel each;

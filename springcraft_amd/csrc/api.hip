@@ -474,9 +474,10 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
 
 // debugging entry point (include/springcraft_hip_debug.h)
 int sc_dbg_set_chase(sc_ctx* ctx, int mode, int give_up_after) {
-  if (!ctx || mode < -1 || mode > 4 || give_up_after < 0) return SC_ERR_INVALID_ARG;
-  // 3 / 4: persistent always, in the pair form / with one sweep per workgroup (2: always, the form by size)
-  ctx->chase_form = mode == 3 ? 1 : (mode == 4 ? 0 : -1);
+  if (!ctx || mode < -1 || mode > 5 || give_up_after < 0) return SC_ERR_INVALID_ARG;
+  // 3 / 4 / 5: persistent always, in the pair form / with one sweep per workgroup, a matrix on one XCD / with one sweep per
+  // workgroup and the workgroups of a matrix on all XCDs ("spread": fewer matrices than XCDs only); 2: always, the form by size
+  ctx->chase_form = mode == 3 ? 1 : (mode == 4 ? 0 : (mode == 5 ? 2 : -1));
   if (mode > 2) mode = 2;
   ctx->chase_mode = mode;
   ctx->chase_give_up = give_up_after;

@@ -66,7 +66,7 @@ struct sc_ctx {
   // entry sc_dbg_set_chase (-1: SPRINGCRAFT_BULGE_PERSISTENT or the size rule; 0 / 1 / 2 as that variable).
   int chase_ok = -1;
   int chase_mode = -1, chase_give_up = 0;
-  int chase_form = -1;   // debug entry: 1 = pair form, 0 = one sweep per workgroup, -1 = by size
+  int chase_form = -1;   // debug entry: 1 = pair form, 0 = one sweep per workgroup, 2 = that with a matrix' workgroups on all XCDs, -1 = by size
   // XCDs of this device as a probe launch saw them (distinct XCC_ID values; 0 = not probed yet), and whether
   // k_bulge_pair's dynamic LDS size has been raised on THIS context's device (-1 = not tried, 0 = refused, 1 = set):
   // the attribute is per device, a process may own contexts on several

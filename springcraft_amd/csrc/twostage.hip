@@ -1607,6 +1607,16 @@ constexpr int kChaseCtlInts = 32;
 // entry from the band instead.
 constexpr int kEarlyRing = 8;
 __device__ __forceinline__ void st16(void* p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st16_sc1(void* p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// a band entry as the chase's workgroups hand it on.  SPREAD = 0: all workgroups of a matrix sit behind ONE L2, a plain
+// store (drained before the counter moves) is what the consumer's sc1 load finds there.  SPREAD = 1 (round 6: one large
+// matrix chased from every XCD): a write-through store at agent scope, which a consumer on another XCD reads from memory
+// with its sc1 load -- the pair MI355X_MICROARCH.md lists as valid without any fence (k_panel_coop's records use it too)
+template <int SPREAD>
+__device__ __forceinline__ void st_band(gdptr p, double v) {
+  if (SPREAD) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 __device__ __forceinline__ v4i ld16_l2(const void* p) {
   v4i r;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
@@ -1639,6 +1649,11 @@ __device__ unsigned long long g_chase_stamps[16];
 #define CHASE_STAMP(i)
 #define CHASE_STAMP_WRITE
 #endif
+// SPREAD = 1 (round 6): the workgroups of ONE matrix on all XCDs -- the launch passes nxcd = 1, so every workgroup
+// counts as "XCD 0" and serves every matrix; band stores and the early records are written through at agent scope
+// (st_band).  For a few large matrices (config C5: one n = 24000 matrix has ~188 tasks per wavefront, three times the
+// workgroups one XCD holds): until round 5 those took one launch per wavefront (48 000 launches of 8.7 us).
+template <int SPREAD>
 __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_all, SbLayout SL, int batch, int W, int nxcd,
                                                      int* __restrict__ progress, int* __restrict__ next_sweep,
                                                      int* __restrict__ ctl, int give_up_after, v4i* __restrict__ early) {
@@ -1826,7 +1841,8 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
               s_tau = h.tau; s_beta = h.beta;
               if (early) {   // the record of this task: all its successor in sweep s + 1 needs to start on
                 const unsigned long long bb = (unsigned long long)__double_as_longlong(h.beta);
-                st16(early + ((size_t)b * n + s) * kEarlyRing + (k & (kEarlyRing - 1)), v4i{(int)(unsigned)bb, (int)(unsigned)(bb >> 32), k + 1, 0});
+                if (SPREAD) st16_sc1(early + ((size_t)b * n + s) * kEarlyRing + (k & (kEarlyRing - 1)), v4i{(int)(unsigned)bb, (int)(unsigned)(bb >> 32), k + 1, 0});
+                else st16(early + ((size_t)b * n + s) * kEarlyRing + (k & (kEarlyRing - 1)), v4i{(int)(unsigned)bb, (int)(unsigned)(bb >> 32), k + 1, 0});
               }
             }
           }
@@ -1849,7 +1865,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
             const int jj = q * 16 + c;
             double e = t16[c] - vn[i] * u[jj];
             if (jj == 0) e = i == 0 ? s_beta : 0.0;
-            if (i < L) ebase_k[(unsigned)((kB + i - jj) + jj * kLdab)] = e;
+            if (i < L) st_band<SPREAD>(ebase_k + (unsigned)((kB + i - jj) + jj * kLdab), e);
           }
         } else {
           gdptr col_s = wave_uniform(ab + (size_t)s * kLdab);
@@ -1866,7 +1882,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
           CHASE_STAMP(4)
           CHASE_SECOND_WAIT()
           CHASE_STAMP(5)
-          if (tid < L) col_s[(unsigned)(1 + tid)] = tid == 0 ? s_beta : 0.0;
+          if (tid < L) st_band<SPREAD>(col_s + (unsigned)(1 + tid), tid == 0 ? s_beta : 0.0);
         }
 #undef CHASE_SECOND_WAIT
         // ---- diagonal block (after the second wait its last row is in the band)
@@ -1906,7 +1922,7 @@ __global__ __launch_bounds__(256, 2) void k_bulge_chase(double* __restrict__ sb_
         CHASE_STAMP(8)
         for (int jj = q * 16; jj < q * 16 + 16; ++jj)
           if (i >= jj && i < L)
-            colbase_k[(unsigned)((i - jj) + jj * kLdab)] = D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj];
+            st_band<SPREAD>(colbase_k + (unsigned)((i - jj) + jj * kLdab), D[i * LD + jj] - vn[i] * u[jj] - u[i] * vn[jj]);
         if (tid < L) vd[(size_t)tid * kG] = vn[tid];
         if (tid == 0) sb[SL.tau2 + dia * kG + cc] = tau_now;
         tau_p = tau_now;
@@ -4502,15 +4518,23 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const bool pair = ctx->chase_form >= 0 ? (ctx->chase_form == 1 && pair_attr)
                                            : use_pair && pair_attr &&
                                                  (force_pair == 2 || (work > 1100 && batch >= 8 && pair_measured));
+    // Round 6, "spread": a few LARGE matrices (fewer than XCDs, n > 6144 -- config C5's single n = 24000 matrix has ~188
+    // tasks per wavefront, three times the workgroups one XCD holds) are chased by k_bulge_chase<1> from ALL XCDs, their
+    // band handed on by write-through stores; until round 5 they took one launch per wavefront.  SPRINGCRAFT_BULGE_SPREAD =
+    // 0 / 1: never / for every chase with fewer matrices than XCDs (tests).
+    static const int env_spread = [] { const char* e = getenv("SPRINGCRAFT_BULGE_SPREAD"); return e ? atoi(e) : -1; }();
+    // (debug entry sc_dbg_set_chase: mode 5 forces it, modes 3 / 4 keep it off)
+    const bool spread = !pair && batch < ctx->nxcd &&
+                        (ctx->chase_form == 2 || (ctx->chase_form < 0 && env_spread != 0 && (env_spread == 1 || n > 6144)));
     const bool want_chase =
-        persist == 2 || (persist == 1 && (pair || (work <= 2800 && (batch >= 8 || n <= 6144))));
+        persist == 2 || (persist == 1 && (pair || spread || (work <= 2800 && (batch >= 8 || n <= 6144))));
     // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):
     // every further attempt could cost another bound's worth of spinning before the fallback
     // XCDs of this device: the kernels bind matrix b to XCD b mod nxcd (an MI355X in SPX mode has 8 XCDs of 32 CUs; a
     // partition of it has fewer, and a matrix bound to an XCD that is not there would never be claimed)
     // (counted on the device, not derived from the CU count: ADVICE round 4)
     if (ctx->nxcd <= 0) SC_TRY(probe_xcd_count(ctx, st));
-    const int nxcd = ctx->nxcd;
+    const int nxcd = spread ? 1 : ctx->nxcd;   // (spread: every workgroup counts as "XCD 0" and serves every matrix)
     if (want_chase && ctx->num_cus > 0 && (ctx->chase_ok != 0 || persist == 2)) {
       int per_cu = 0;
       if (pair) {
@@ -4518,7 +4542,9 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_pair<0>, 512, kPairLdsBytes);
         if (oe != hipSuccess) per_cu = 0;
       } else {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase, 256, 0) != hipSuccess) per_cu = 0;
+        const hipError_t oe = spread ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase<1>, 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bulge_chase<0>, 256, 0);
+        if (oe != hipSuccess) per_cu = 0;
       }
       const int slots_per_xcd = per_cu * ctx->num_cus / nxcd;
       const int mpx = (batch + nxcd - 1) / nxcd;   // matrices per XCD (XCD 0 has the most)
@@ -4555,8 +4581,12 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
                              PairLayout{SL.n, SL.slab, SL.ab, SL.vd, SL.tau2}, batch, W, nxcd, d_prog, d_next, d_ctl,
                              ctx->chase_give_up, pair_early);
         else
-          hipLaunchKernelGGL(k_bulge_chase, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
-                             d_next, d_ctl, ctx->chase_give_up, d_early);
+          if (spread)
+            hipLaunchKernelGGL(k_bulge_chase<1>, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
+                               d_next, d_ctl, ctx->chase_give_up, d_early);
+          else
+            hipLaunchKernelGGL(k_bulge_chase<0>, dim3((unsigned)grid), dim3(256), 0, st, d_sb_ws, SL, batch, W, nxcd, d_prog,
+                               d_next, d_ctl, ctx->chase_give_up, d_early);
         const hipError_t le = hipGetLastError();
         t_bulge.stop();
         if (le != hipSuccess && pair) {

@@ -208,12 +208,13 @@ def _lib_dbg():
 
 @pytest.mark.parametrize("n,batch", [(1200, 8), (1030, 32), (1030, 1), (520, 3), (259, 9), (322, 2)])
 @pytest.mark.parametrize("give_up", [0, 5, 100])
-@pytest.mark.parametrize("form", [3, 4])
+@pytest.mark.parametrize("form", [3, 4, 5])
 def test_persistent_chase_and_resume(n, batch, give_up, form):
     """
     (form 3: two sweeps per workgroup through LDS, k_bulge_pair -- the give-up then also exercises the write-back of the
-    LDS slots; form 4: one sweep per workgroup, k_bulge_chase; orders with partial last blocks and an odd sweep count
-    included.)
+    LDS slots; form 4: one sweep per workgroup, k_bulge_chase; form 5, round 6: the same with the workgroups of a matrix on
+    ALL XCDs, band entries handed on by write-through stores -- with eight matrices and more it is form 4; orders with
+    partial last blocks and an odd sweep count included.)
     The persistent bulge chase (forced on through the debug entry) as ONE batched solve -- several matrices per XCD at
     batch 32, one XCD without a matrix at batch 3 -- and the event counters of the context: without the test hook the
     chase must finish every sweep itself (no time-out, no take-over by the per-wavefront launches); with the hook
