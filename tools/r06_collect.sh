@@ -39,7 +39,20 @@ out = {"kernel": "k_bulge_pair<0> (unchanged since round 4)", "n": 6000, "batch"
 json.dump(out, open("profiles/r06_bulge_pmc_fetch_write.json", "w"), indent=1)
 print("bulge traffic / task bytes:", out["traffic_over_task_bytes"])
 PY
-cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt $F/test_matrix_4.txt | grep -v "^part" > $P/r06_test_matrix.txt
+{ echo "# bash tools/r06_final.sh c1 | c2 | c3 | c4 (tools/test_matrix.sh in four parts), then c0.  35 rows."
+  echo "# Three rows FAILED in their first run; the failing output is kept below, each with what was changed, and part c0 re-ran them"
+  echo "# (and the two rows added after the spread chase was built) on the final build:"
+  echo "#  * SPRINGCRAFT_BULGE_PERSISTENT=0 ... STREAMS=1: test_device_solve_only_enqueues_at_n6000 asserted three persistent-chase launches,"
+  echo "#    which that row switches off -- the test skips there now (a test that contradicts the override, not a product fault)."
+  echo "#  * SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3: test_config3_batched_automatic_path"
+  echo "#    (the same structure at two batch positions must give identical eigenvalues): with three parts of unequal size k_symm3 took a"
+  echo "#    panel for one part and declined it for a smaller one (too few work items), which then ran the triangular-operand launches --"
+  echo "#    both right, other summation orders.  Fix (twostage.hip): ONE decision per panel, made for the smallest part, for all parts."
+  echo "#  * SPRINGCRAFT_SYMM3=0: the unit tests of k_symm3 ran with the kernel switched off -- they skip there now."
+  cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt $F/test_matrix_4.txt | grep -v "^part"
+  echo "# ---- part c0: re-runs after the fixes + the two later rows"
+  grep -v "^part" $F/test_matrix_0.txt; } > $P/r06_test_matrix.txt
+cp $F/spread_chase.txt $P/r06_spread_chase.txt
 grep -v "^rc 0$" $F/pair_stamps.txt | grep -v amdgpu.ids > $P/r06_pair_stamps.txt
 cp $F/pair_ab.txt $P/r06_pair_ab.txt
 { echo "== tools/symm3_bench.py (k_symm3 alone, random operands; last two lines: every column of A redirected to one hot column)"; cat $F/symm3_bench.txt

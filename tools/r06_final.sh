@@ -4,11 +4,12 @@
 #   bash tools/r06_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
 #                               runs) of k_bt2_apply (bytes, MFMA-pipe occupancy at the benchmarked batch), of k_symm3 and
 #                               of k_bulge_pair (bytes)
-#   bash tools/r06_final.sh c1 | c2 | c3 | c4   the test matrix (tools/test_matrix.sh), in four parts
+#   bash tools/r06_final.sh c1 | c2 | c3 | c4   the test matrix (tools/test_matrix.sh), in four parts; c0: the rows that failed
+#                               in their first run (after the fixes) and the two rows added later
 #   bash tools/r06_final.sh d   k_bulge_pair: per-phase stamps without / with loader waves and with the early look, the
 #                               diagnostic variants (512-thread form under the 768-thread form's register budget; loader
 #                               waves that request nothing), same-box A/B of the three forms on the bench step
-#   bash tools/r06_final.sh e   k_symm3: micro-bench (random and zero-like "hot" operands), loader-wave stamps, on / off in
+#   bash tools/r06_final.sh e   the spread chase on / off (C5, n = 12000, one N = 2000 structure); k_symm3: micro-bench (random and zero-like "hot" operands), loader-wave stamps, on / off in
 #                               the bench step and in C5 / C4 / C2; trailing update on 224 / 256 workgroups; D&C per level
 #   bash tools/r06_final.sh f   two-rank rehearsal on the shared GPU (bench.py --gpus 2, gloo)
 # Everything lands in gpurun_out/r06_final/; what is to be judged is copied to profiles/r06_* (tools/r06_collect.sh).
@@ -51,6 +52,15 @@ elif [ $part = c1 ] || [ $part = c2 ] || [ $part = c3 ] || [ $part = c4 ]; then
   k=${part#c}
   bash tools/test_matrix.sh $k 4 > $OUT/test_matrix_$k.txt 2>&1
   cat $OUT/test_matrix_$k.txt
+elif [ $part = c0 ]; then
+  T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py"
+  row() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q -rf 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|error" | tail -4; }
+  { row SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=1 SPRINGCRAFT_STAGE1_STREAMS=1
+    row SPRINGCRAFT_BULGE_PERSISTENT=0 SPRINGCRAFT_BULGE_STREAMS=3 SPRINGCRAFT_STAGE1_STREAMS=3
+    row SPRINGCRAFT_SYMM3=0
+    row SPRINGCRAFT_BULGE_SPREAD=1
+    row SPRINGCRAFT_BULGE_SPREAD=0; } > $OUT/test_matrix_0.txt 2>&1
+  cat $OUT/test_matrix_0.txt
 elif [ $part = d ]; then
   bash tools/r06_pair_stamps.sh > $OUT/pair_stamps.txt 2>&1
   { echo "== early look (SPRINGCRAFT_PAIR_EARLY=1), no loader waves";
@@ -70,6 +80,12 @@ elif [ $part = e ]; then
   cat $OUT/syr2k_wgs.txt
   ENVS="SPRINGCRAFT_SYMM3=0;SPRINGCRAFT_SYMM3=1" bash tools/r06_cfgs.sh > $OUT/symm3_cfgs.txt 2>&1
   grep -v "^    {" $OUT/symm3_cfgs.txt
+  { ENVS="SPRINGCRAFT_BULGE_SPREAD=0;X=default" CFGS="c5" bash tools/r06_cfgs.sh 2>&1 | grep -v "^    {.bt2"
+    echo "== one structure at a time (tools/latency_phases.py), SPRINGCRAFT_BULGE_SPREAD=1: the N = 2000 chase from all XCDs"
+    SPRINGCRAFT_BULGE_SPREAD=1 timeout -k 10 300 python tools/latency_phases.py 2>&1 | grep "two_stage=True" | cut -c1-400
+    echo "== n = 12000 (bench.py --config c5 --n-atoms 4000), SPRINGCRAFT_BULGE_SPREAD = 0 / default"
+    for e in SPRINGCRAFT_BULGE_SPREAD=0 X=default; do env $e timeout -k 10 300 python bench.py --config c5 --n-atoms 4000 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('  $e', round(d['ms_per_step'],1), 'ms per solve, bulge chasing', round(d['phases_ms_profiled_step'].get('bulge_chasing_ms',0),1))"; done; } > $OUT/spread_chase.txt 2>&1
+  cat $OUT/spread_chase.txt
   bash tools/r06_dc_levels.sh > $OUT/dc_levels.txt 2>&1
   cat $OUT/dc_levels.txt
   bash tools/r06_probe_i8.sh > /dev/null 2>&1; cp gpurun_out/r06/probe_i8_emulation.txt $OUT/probe_i8_emulation.txt; tail -12 $OUT/probe_i8_emulation.txt
