@@ -4518,14 +4518,17 @@ int sytrd_2stage_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, in
     const bool pair = ctx->chase_form >= 0 ? (ctx->chase_form == 1 && pair_attr)
                                            : use_pair && pair_attr &&
                                                  (force_pair == 2 || (work > 1100 && batch >= 8 && pair_measured));
-    // Round 6, "spread": a few LARGE matrices (fewer than XCDs, n > 6144 -- config C5's single n = 24000 matrix has ~188
+    // Round 6, "spread": a few LARGE matrices (fewer than XCDs, n > 4500 -- config C5's single n = 24000 matrix has ~188
     // tasks per wavefront, three times the workgroups one XCD holds) are chased by k_bulge_chase<1> from ALL XCDs, their
-    // band handed on by write-through stores; until round 5 they took one launch per wavefront.  SPRINGCRAFT_BULGE_SPREAD =
-    // 0 / 1: never / for every chase with fewer matrices than XCDs (tests).
+    // band handed on by write-through stores; until round 5 the largest took one launch per wavefront.  One matrix on one XCD
+    // against all XCDs, bulge chasing in ms (tools/spread_sweep.py, profiles/r06_spread_chase.txt): n = 2100 24.3 / 26.4, 3000
+    // 35.2 / 38.2, 4200 54.0 / 53.4, 6000 84.2 / 76.9 (2 and 4 matrices: 86 / 78), 9000 144.6 / 116.3, 12000 195.6 / 156.3, 24000
+    // (per-wavefront launches) 418 / 318.  SPRINGCRAFT_BULGE_SPREAD = 0 / 1: never / for every chase with fewer matrices than
+    // XCDs (tests).
     static const int env_spread = [] { const char* e = getenv("SPRINGCRAFT_BULGE_SPREAD"); return e ? atoi(e) : -1; }();
     // (debug entry sc_dbg_set_chase: mode 5 forces it, modes 3 / 4 keep it off)
     const bool spread = !pair && batch < ctx->nxcd &&
-                        (ctx->chase_form == 2 || (ctx->chase_form < 0 && env_spread != 0 && (env_spread == 1 || n > 6144)));
+                        (ctx->chase_form == 2 || (ctx->chase_form < 0 && env_spread != 0 && (env_spread == 1 || n > 4500)));
     const bool want_chase =
         persist == 2 || (persist == 1 && (pair || spread || (work <= 2800 && (batch >= 8 || n <= 6144))));
     // a context whose chase ran into its time-out is not asked again (ctx->chase_ok = 0, counted in chase_timeouts):

@@ -33,7 +33,7 @@ v = [int(x) for x in buf]
 steps = max(1, v[9])   # the stamps cover the common steps (pair_step_full) only
 names = ["wait + barrier [0]", "block reads (A: loads or landed image, B: slots + store drain) + [1]", "E right + reflector [2,3]",
          "column sums + u + D image [4,5]", "E left + D products [6]", "w [7]", "D update (+ stores)"]
-print(f"rc {rc}  N = {n_atoms} x {B}  loader waves {os.environ.get('SPRINGCRAFT_PAIR_LOADER', '1')}: bulge chasing "
+print(f"rc {rc}  N = {n_atoms} x {B}  loader waves {os.environ.get('SPRINGCRAFT_PAIR_LOADER', '0')}: bulge chasing "
       f"{t['bulge_chasing_ms']:.1f} ms, {v[8]} steps ({v[9]} common), "
       f"counters launches {solver.ctx.counter('chase_launches')} timeouts {solver.ctx.counter('chase_timeouts')}")
 print(f"  {'cycles per common step':72s} {'thread 0 (A)':>12s} {'thread 256 (B)':>14s}")

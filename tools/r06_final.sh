@@ -81,8 +81,8 @@ elif [ $part = e ]; then
   ENVS="SPRINGCRAFT_SYMM3=0;SPRINGCRAFT_SYMM3=1" bash tools/r06_cfgs.sh > $OUT/symm3_cfgs.txt 2>&1
   grep -v "^    {" $OUT/symm3_cfgs.txt
   { ENVS="SPRINGCRAFT_BULGE_SPREAD=0;X=default" CFGS="c5" bash tools/r06_cfgs.sh 2>&1 | grep -v "^    {.bt2"
-    echo "== one structure at a time (tools/latency_phases.py), SPRINGCRAFT_BULGE_SPREAD=1: the N = 2000 chase from all XCDs"
-    SPRINGCRAFT_BULGE_SPREAD=1 timeout -k 10 300 python tools/latency_phases.py 2>&1 | grep "two_stage=True" | cut -c1-400
+    echo "== a few matrices, one XCD per matrix (SPRINGCRAFT_BULGE_SPREAD=0) against all XCDs for every matrix (=1): tools/spread_sweep.py"
+    for sp in 0 1; do SPRINGCRAFT_BULGE_SPREAD=$sp timeout -k 10 400 python tools/spread_sweep.py 2>/dev/null; done
     echo "== n = 12000 (bench.py --config c5 --n-atoms 4000), SPRINGCRAFT_BULGE_SPREAD = 0 / default"
     for e in SPRINGCRAFT_BULGE_SPREAD=0 X=default; do env $e timeout -k 10 300 python bench.py --config c5 --n-atoms 4000 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('  $e', round(d['ms_per_step'],1), 'ms per solve, bulge chasing', round(d['phases_ms_profiled_step'].get('bulge_chasing_ms',0),1))"; done; } > $OUT/spread_chase.txt 2>&1
   cat $OUT/spread_chase.txt
