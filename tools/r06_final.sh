@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-6 evidence on one GPU box, in parts (a gpurun call is limited to 20 minutes):
 #   bash tools/r06_final.sh a   the -m gpu suite with durations, the four bench lines (C3 with the CPU baseline), latencies
+#   bash tools/r06_final.sh ab  the default bench line and the rocprofv3 kernel statistics of the same command on ONE box
 #   bash tools/r06_final.sh b   rocprofv3 kernel statistics of the default bench command; PMC passes (counters only, separate
 #                               runs) of k_bt2_apply (bytes, MFMA-pipe occupancy at the benchmarked batch), of k_symm3 and
 #                               of k_bulge_pair (bytes)
@@ -30,6 +31,15 @@ if [ $part = a ]; then
   done
   timeout -k 10 300 python tools/latency_phases.py > $OUT/latency.txt 2>&1 || exit 1
   grep -v amdgpu.ids $OUT/latency.txt
+elif [ $part = ab ]; then
+  # the default bench line and the rocprofv3 kernel statistics of the same command on ONE box (boxes differ by 3 - 5 %)
+  timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+  python tools/show_bench.py $OUT/bench.json
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench --output-format csv -- \
+     python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err) || { tail -5 $OUT/bench_under_rocprof.err; exit 1; }
+  rm -f $OUT/prof/*kernel_trace.csv $OUT/prof/*/*kernel_trace.csv
+  cp $(ls -t $OUT/prof/*kernel_stats.csv $OUT/prof/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_bench.csv
+  head -4 $OUT/rocprofv3_kernel_stats_bench.csv | cut -c1-200
 elif [ $part = b ]; then
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench --output-format csv -- \
      python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err) || { tail -5 $OUT/bench_under_rocprof.err; exit 1; }
