@@ -305,6 +305,8 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
  *   "xcd_count"        XCDs of the device as a probe launch saw them (0: not probed yet)
  *   "gemm3_launches"   launches the role-split persistent GEMM (k_gemm3) took
  *   "symm3_launches"   launches of the band reduction's symmetric product X = A22 V as one role-split kernel (k_symm3)
+ *   "resident_launches" / "resident_takeovers"   one-stage reductions of one matrix done by the single launch that keeps
+ *                      its rows in LDS (k_sytrd_resident), and those of them its take-over kernel had to do instead
  *   "panel_coop_launches"   panel factorisations by the cooperative kernel (k_panel_coop: several workgroups of one launch)
  *   "panel_coop_timeouts"   panels (per matrix) the cooperative kernel gave up on -- a wait between its workgroups ran
  *                      into its bound; expected to stay 0 -- and the take-over launch behind it factored instead: the

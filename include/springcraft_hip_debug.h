@@ -116,6 +116,14 @@ int sc_dbg_set_panel_coop(sc_ctx* ctx, int min_rows);
  * and every later one, counted in "panel_coop_timeouts". */
 int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel);
 
+/* One-launch tridiagonalisation of ONE matrix whose rows stay in LDS (k_sytrd_resident, tridiag.hip; one-stage path,
+ * the trailing matrix of order <= 2048): mode 0 = never, 1 / -1 = the default rule (SPRINGCRAFT_RESIDENT).  hook: tests,
+ * 1 = the roll call of its workgroups fails (nothing stored yet: k_sytrd_takeover reduces the matrix), 2 + c = the
+ * exchange of step c fails (the take-over restores the matrix from its other triangle and starts again); 0 = none.
+ * workgroups: 0 = by size, else a power of two (SPRINGCRAFT_RESIDENT_WGS).  Counters "resident_launches" /
+ * "resident_takeovers".  tests/test_eigh_gpu.py */
+int sc_dbg_set_resident(sc_ctx* ctx, int mode, int hook, int workgroups);
+
 #ifdef __cplusplus
 }
 #endif

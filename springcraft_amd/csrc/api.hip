@@ -97,6 +97,8 @@ int sc_collect_events(sc_ctx* ctx) {
   ctx->cnt_chase_sweeps += (long long)h[4];
   ctx->cnt_coop_timeouts += (long long)h[5];
   ctx->cnt_chase_incomplete += (long long)h[6];
+  ctx->cnt_resident_takeovers += (long long)h[7];
+  if (h[7]) ctx->resident_ok = 0;
   // a context whose persistent kernels ran into a bound keeps to the launch-per-wavefront / chunked forms from here on
   if (h[3] || h[6]) ctx->chase_ok = 0;
   if (h[5]) ctx->coop_ok = 0;
@@ -456,6 +458,8 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   else if (k == "xcd_count") *value = ctx->nxcd;
   else if (k == "gemm3_launches") *value = ctx->cnt_gemm3_launches;
   else if (k == "symm3_launches") *value = ctx->cnt_symm3_launches;
+  else if (k == "resident_launches") *value = ctx->cnt_resident_launches;
+  else if (k == "resident_takeovers") *value = ctx->cnt_resident_takeovers;
   else if (k == "panel_coop_launches") *value = ctx->cnt_coop_launches;
   else if (k == "panel_coop_timeouts") *value = ctx->cnt_coop_timeouts;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
@@ -489,6 +493,15 @@ int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel) {
   if (!ctx || panel < -1) return SC_ERR_INVALID_ARG;
   ctx->coop_fail_panel = panel;
   if (panel >= 0) ctx->coop_ok = -1;
+  return SC_OK;
+}
+
+int sc_dbg_set_resident(sc_ctx* ctx, int mode, int hook, int workgroups) {
+  if (!ctx || mode < -1 || mode > 1 || hook < 0 || workgroups < 0 || workgroups > 256) return SC_ERR_INVALID_ARG;
+  ctx->resident_mode = mode;
+  ctx->resident_hook = hook;
+  ctx->resident_wgs = workgroups;
+  if (mode != 0) ctx->resident_ok = -1;
   return SC_OK;
 }
 

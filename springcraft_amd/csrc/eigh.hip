@@ -44,6 +44,8 @@ size_t tri_slab_doubles(int n, TriLayout* out) {
   L.e = take(n);
   L.tau = take(n);
   L.hscale = take(8);
+  L.rctl = take(8);
+  L.rrec = take(6 * ((n + 63) / 64 * 64));
   L.slab = off;
   if (out) *out = L;
   return (size_t)off;

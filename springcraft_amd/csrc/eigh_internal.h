@@ -19,7 +19,11 @@ struct TriLayout {
   long long d, e, tau;  // tridiagonal + reflector scalars (n each)
   long long hscale;     // [0] = 1/(alpha - beta) of the current column (written by k_symv_tiles);
                         // [1] = bit pattern of max |a_ij|, [2] = power-of-two factor the matrix was scaled by
+  long long rctl;       // k_sytrd_resident: control words (16 ints), directly followed by
+  long long rrec;       // its exchange records, 3 buffers x (n rounded up to 64) x 16 bytes
 };
+// bytes from rctl that a solve sets to 0xFF before k_sytrd_resident (control words "undecided", records "empty")
+inline size_t tri_resident_bytes(int n) { return sizeof(double) * (8 + (size_t)6 * ((n + 63) / 64 * 64)); }
 
 // d_a: (batch) n x n column-major, lower triangle valid after the mirror pass; on exit column c holds
 // v_c (explicit leading 1) in rows c+1.., and ws holds d, e, tau.

@@ -70,6 +70,17 @@ __device__ __forceinline__ double sum_partials(const double* p, int cnt, double*
   return s;
 }
 
+// Sum over a workgroup of any size (a multiple of 64 threads, <= 1024): result in every thread; contains barriers.
+__device__ __forceinline__ double block_sum_any(double v, double* sh /*[16]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
 // Rows are tiled in ABSOLUTE blocks of 64 (block B = rows 64B .. 64B+63), not relative to the
 // current column: every 64-row segment then starts on an even row, so with an even matrix order the
 // SYMV tiles can be fetched with 16-byte loads, and the partial-result tables keep the same indexing
@@ -518,6 +529,393 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
   }
 }
 
+
+// ---- one matrix RESIDENT in LDS: the whole tridiagonalisation in one launch (round 6) -------------------------------
+// The reference's own call is ONE structure at a time (anm.py:150-167, proteins of 100 - 1500 residues), and for one
+// matrix of order n <= 2048 the launches above are all latency: 3 dependent launches of 5 - 9 us per column, 25 ms at
+// n = 1536, whatever the kernels inside them do.  Here P <= 256 workgroups of ONE launch keep the matrix on the chip for
+// the whole reduction -- workgroup k holds the FULL rows k, k + P, k + 2P, ... (both triangles, <= 8 rows of <= 2048
+// doubles: <= 128 KB of LDS) -- and run LAPACK's unblocked dsytd2 recurrence with ONE exchange between the workgroups
+// per column:
+//   * every workgroup knows the current reflector v_c (registers: thread t holds the entries j = t, t + 256, ...) and
+//     has y_r = A[r, :] v_c for its own rows from the pass below;
+//   * it publishes, for each own row r, the 16-byte record { tau y_r , A[r, c+1] } (sc1 store: agent scope, visible to
+//     the other XCDs without a fence) and polls the records of ALL rows (sc1 loads; a record is "empty" while it holds
+//     the all-ones pattern, which no finite or NaN result of an arithmetic instruction has);
+//   * from the records EVERY workgroup computes, redundantly and identically, w = w~ - (tau/2)(w~.v) v, the next column
+//     a = A[:, c+1] - v w[c+1] - w (by symmetry A[r, c+1] of row r's owner IS the column entry; v[c+1] = 1), its norm,
+//     the next reflector and tau: two workgroup-level reductions, no second exchange;
+//   * one pass over the own rows in LDS applies the rank-2 update A -= v w^T + w v^T and multiplies the updated rows
+//     with the NEXT reflector in the same sweep (the y of the next column).
+// Three record buffers take turns: a row's owner empties the buffer of step c - 1 after its own poll of step c (by
+// then every workgroup has published step c, i.e. has finished reading step c - 1) and waits for that store before it
+// publishes step c + 1, so a reader of step c + 2 cannot see a record of step c - 1.
+// Workgroup (c mod P) stores column c's reflector / d / e / tau.  The two copies of an off-diagonal element are updated
+// with the operands in a different order and may differ in the last bit: the reduction then is that of a matrix
+// A + E with |E| of the order of the rounding errors of the update itself.
+// All P workgroups must be resident together.  They check it BEFORE anything is stored (roll call: workgroup 0 counts
+// the arrivals within a bound and publishes go / abort in one word that a late comer can only read): after an abort the
+// matrix is untouched and k_sytrd_takeover, enqueued behind every launch, reduces it by one workgroup from memory; it also
+// restarts a reduction that lost a wait in mid-run when the upper triangle still holds the matrix (whole-matrix
+// launches; a trailing-matrix launch reports the failed solve through the status word).
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int kResR = 8;                 // rows per workgroup at most
+constexpr int kResMaxM = 2048;           // order of the (trailing) matrix at most: 8 entries of a vector per thread
+constexpr int kResSmall = 96;            // doubles of LDS besides the rows
+
+struct ResArgs {
+  double* a;              // whole matrices, column-major, leading dimension L.n
+  long long stride_a;
+  double* tri;
+  TriLayout L;
+  int off, m;             // the trailing matrix reduced here: rows / columns off .. off + m - 1
+  int P, logP;            // workgroups per matrix (a power of two)
+  int full;               // both triangles of the trailing matrix hold it (off = 0: straight after prepare_matrix_batched)
+  int hook;               // tests: 1 = the roll call fails, 2 + c = the exchange of step c fails
+  unsigned long long* status;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double res_dpp(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+// eight sums over the 64 lanes at the cost of three (as twostage.hip's wave_reduce8): lane l < 8 returns the total of
+// v[res_reduce8_index(l)]
+__device__ __forceinline__ int res_reduce8_index(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+__device__ __forceinline__ double res_reduce8(const double (&v)[8]) {
+  const int lane = threadIdx.x & 63;
+  double k4[4], k2[2];
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double send = b0 ? v[k] : v[k + 4];
+    k4[k] = (b0 ? v[k + 4] : v[k]) + res_dpp<0xB1>(send);       // lane ^ 1
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double send = b1 ? k4[k] : k4[k + 2];
+    k2[k] = (b1 ? k4[k + 2] : k4[k]) + res_dpp<0x4E>(send);     // lane ^ 2
+  }
+  const double send = b2 ? k2[0] : k2[1];
+  const double from_lo = res_dpp<0x114>(send), from_hi = res_dpp<0x104>(send);   // lane - 4, lane + 4
+  double r = (b2 ? k2[1] : k2[0]) + (b2 ? from_lo : from_hi);                    // lane ^ 4
+  r += res_dpp<0x128>(r);                                                        // lane ^ 8 inside a row of 16
+  r += __shfl_xor(r, 16);
+  r += __shfl_xor(r, 32);
+  return r;
+}
+__device__ __forceinline__ double res_pair(int lo, int hi) {
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ void res_store(v4i* p, double x, double y) {
+  const unsigned long long bx = (unsigned long long)__double_as_longlong(x), by = (unsigned long long)__double_as_longlong(y);
+  const v4i r = {(int)(unsigned)bx, (int)(unsigned)(bx >> 32), (int)(unsigned)by, (int)(unsigned)(by >> 32)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int m = g.m, lp = g.logP, P = g.P, n = g.L.n;
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int LDr = (m + 63) & ~63;
+  const int R = k < m ? ((m - 1 - k) >> lp) + 1 : 0;        // own rows k, k + P, ...
+  const int Rmax = ((m - 1) >> lp) + 1;
+  double* Aw = g.a + (size_t)blockIdx.y * g.stride_a;
+  double* A = Aw + (size_t)g.off * n + g.off;               // the trailing matrix (leading dimension n)
+  double* tri = g.tri + (size_t)blockIdx.y * g.L.slab;
+  int* ctl = reinterpret_cast<int*>(tri + g.L.rctl);        // [0] -1 undecided / 1 go / 2 abort, [1] arrivals - 1, [2] 1 = a wait was lost
+  v4i* rec = reinterpret_cast<v4i*>(tri + g.L.rrec);
+  double* rows = sm;                                         // [Rmax][LDr]
+  double* red = rows + (size_t)Rmax * LDr;                   // [4] [4] : partial sums of the two reductions
+  double* red8 = red + 8;                                    // [4][8]
+  double* bc = red8 + 32;                                    // [4]   values every thread needs
+  double* vrow = bc + 4;                                     // [8]   v_c, w_c at the own rows
+  double* wrow = vrow + 8;
+  int* s_flag = reinterpret_cast<int*>(wrow + 8);            // [0] go, [1] dead
+
+  // ---- the own rows -> LDS.  Straight after prepare_matrix_batched both triangles hold the matrix (the mirror pass
+  // copies, it does not move), so a row is contiguous in memory; the scaling pass touches the lower triangle only, and a
+  // trailing matrix behind SYR2K updates lives in the lower triangle only: the left part of a row is then gathered.
+  {
+    const double f = tri[g.L.hscale + 2];
+    const bool bad = *reinterpret_cast<const unsigned long long*>(tri + g.L.hscale + 3) != 0ull;
+    const bool full = g.full && f == 1.0 && !bad;
+    for (int i = 0; i < R; ++i) {
+      const int r = k + (i << lp);
+      for (int j = tid; j < LDr; j += 256) {
+        double x = 0.0;
+        if (j < m) x = (full || j >= r) ? A[(size_t)r * n + j] : A[(size_t)j * n + r];
+        rows[(size_t)i * LDr + j] = x;
+      }
+    }
+  }
+  double v[Q], w[Q], a[Q], vn[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = tid + 256 * q;
+    v[q] = 0.0;
+    w[q] = 0.0;
+    a[q] = j < m ? A[j] : 0.0;          // column 0 (lower triangle)
+  }
+  // ---- roll call (behind every read of the matrix: workgroup 0 stores column 0's reflector before the first exchange)
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int dec = -1;
+    long spins = 0;
+    if (k == 0) {
+      bool all = false;
+      while (!all && spins < (1L << 17)) {
+        all = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P - 1;
+        ++spins;
+        if (!all) __builtin_amdgcn_s_sleep(8);
+      }
+      if (g.hook == 1) all = false;
+      const int want = all ? 1 : 2;
+      const int old = atomicCAS(&ctl[0], -1, want);
+      dec = old == -1 ? want : old;
+    } else {
+      while ((dec = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) {
+        if (++spins > (1L << 21)) {
+          const int old = atomicCAS(&ctl[0], -1, 2);
+          dec = old == -1 ? 2 : old;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    s_flag[0] = dec;
+    s_flag[1] = 0;
+  }
+  __syncthreads();
+  if (s_flag[0] != 1) return;
+
+  double tau = 0.0, yown = 0.0;
+  const int myr = k + (tid << lp);      // the row thread tid < R publishes
+  double* const d_out = tri + g.L.d + g.off;
+  double* const e_out = tri + g.L.e + g.off;
+  double* const tau_out = tri + g.L.tau + g.off;
+
+  for (int c = -1; c <= m - 3; ++c) {
+    if (c >= 0) {
+      v4i* rb = rec + (size_t)(c % 3) * LDr;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the emptying store of the previous step, see above)
+      if (g.hook == 2 + c && k == 0 && tid == 0) atomicExch(&ctl[2], 1);
+      if (tid < R && myr > c) res_store(rb + myr, tau * yown, rows[(size_t)tid * LDr + c + 1]);
+      // ---- poll the records of the rows j > c (all loads of a round in flight together; unconditional, a lane without
+      // a record of its own re-reads a neighbour's: a predicated load would let the compiler touch the register early)
+      bool need[Q];
+      const v4i* ptr[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int j = tid + 256 * q;
+        need[q] = j > c && j < m;
+        ptr[q] = rb + (need[q] ? j : c + 1);
+      }
+      v4i r4[Q];
+      long spins = 0;
+      bool lost = false;
+      while (true) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r4[q]) : "v"(ptr[q]) : "memory");
+        if constexpr (Q == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0])::"memory");
+        if constexpr (Q == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1])::"memory");
+        if constexpr (Q == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3])::"memory");
+        if constexpr (Q == 6)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5])::"memory");
+        if constexpr (Q == 8)
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5]), "+v"(r4[6]), "+v"(r4[7])::"memory");
+        bool fresh = true;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) fresh = fresh && ((r4[q].x & r4[q].y) != -1);   // (a lane without a record reads a needed one)
+        if (__all(fresh)) break;
+        ++spins;
+        if ((spins & 63) == 0 && __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { lost = true; break; }
+        if (spins > (1L << 22)) {
+          if (lane == 0 && atomicExch(&ctl[2], 1) != 1) { ctl[3] = c; ctl[4] = k; ctl[5] = wave; }
+          lost = true;
+          break;
+        }
+      }
+      if (lost && lane == 0) s_flag[1] = 1;
+      // the buffer of step c - 1 is free: every workgroup has published step c, so it has read step c - 1
+      if (tid < R && myr > c) res_store(rec + (size_t)((c + 2) % 3) * LDr + myr, res_pair(-1, -1), res_pair(-1, -1));
+      double dp = 0.0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int j = tid + 256 * q;
+        w[q] = need[q] ? res_pair(r4[q].x, r4[q].y) : 0.0;     // w~ = tau y
+        a[q] = need[q] ? res_pair(r4[q].z, r4[q].w) : 0.0;     // A[j, c+1] before this step's update
+        dp += w[q] * v[q];
+        if (j == c + 1) bc[0] = w[q];
+      }
+      dp = wave_sum(dp);
+      if (lane == 0) red[wave] = dp;
+      lds_barrier();
+      if (s_flag[1]) return;
+      const double alpha2 = -0.5 * tau * ((red[0] + red[1]) + (red[2] + red[3]));
+      const double wc1 = bc[0] + alpha2;                       // w[c+1]  (v[c+1] = 1)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (need[q]) {
+          w[q] += alpha2 * v[q];
+          a[q] = (a[q] - v[q] * wc1) - w[q];
+        }
+      }
+    }
+    // ---- column c + 1 of the updated matrix is a[c+1 ..]: its diagonal entry, the pivot a[c+2], the norm below it
+    double np = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = tid + 256 * q;
+      if (j >= c + 3 && j < m) np += a[q] * a[q];
+      if (j == c + 2) bc[1] = a[q];
+      if (j == c + 1) bc[2] = a[q];
+      const int dj = j - k;
+      if (dj >= 0 && (dj & (P - 1)) == 0 && j < m) {           // an own row: this step's v and w at it, for the update below
+        vrow[dj >> lp] = v[q];
+        wrow[dj >> lp] = w[q];
+      }
+    }
+    np = wave_sum(np);
+    if (lane == 0) red[4 + wave] = np;
+    lds_barrier();
+    const double xn2 = (red[4] + red[5]) + (red[6] + red[7]);
+    const HH h = householder(bc[1], xn2);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = tid + 256 * q;
+      vn[q] = (j > c + 2 && j < m) ? h.scale * a[q] : (j == c + 2 ? 1.0 : 0.0);
+    }
+    if (k == ((c + 1) & (P - 1))) {
+      if (c + 1 <= m - 3) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int j = tid + 256 * q;
+          if (j >= c + 2 && j < m) A[(size_t)(c + 1) * n + j] = vn[q];
+        }
+      }
+      if (tid == 0) {
+        d_out[c + 1] = bc[2];
+        e_out[c + 1] = h.beta;      // (column m - 2: no entries below the pivot, householder returns beta = the pivot, tau = 0)
+        tau_out[c + 1] = h.tau;
+      }
+    }
+    // ---- own rows >= c + 2, columns >= c + 2: A -= v w^T + w v^T, y = A vn
+    double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < kResR; ++i) {
+      if (i < R && k + (i << lp) >= c + 2) {
+        const double vr = vrow[i], wr = wrow[i];
+        double* row = rows + (size_t)i * LDr;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int j = tid + 256 * q;
+          if (j >= c + 2 && j < m) {
+            double x = row[j];
+            x -= vr * w[q] + wr * v[q];
+            row[j] = x;
+            yp[i] += x * vn[q];
+          }
+        }
+      }
+    }
+    const double ys = res_reduce8(yp);
+    if (lane < 8) red8[wave * 8 + res_reduce8_index(lane)] = ys;
+    lds_barrier();
+    if (tid < 8) yown = (red8[tid] + red8[8 + tid]) + (red8[16 + tid] + red8[24 + tid]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = vn[q];
+    tau = h.tau;
+  }
+  // the last diagonal entry: with the row's owner, written by the thread that reads it here
+  {
+    const int jl = m - 1, dj = jl - k;
+    if (dj >= 0 && (dj & (P - 1)) == 0 && tid == (jl & 255)) d_out[jl] = rows[(size_t)(dj >> lp) * LDr + jl];
+  }
+}
+
+// The take-over of k_sytrd_resident, enqueued behind every one of its launches: ONE workgroup that returns at once unless
+// the roll call was aborted (matrix untouched) or a wait was lost in mid-run (whole-matrix launches: the upper triangle
+// still holds the matrix; a trailing-matrix launch cannot be restarted and fails the solve through the status word).
+// Then LAPACK's dsytd2 from memory on the full symmetric matrix (the other triangle is filled in first), a thread per row:
+// slow -- the matrix is streamed twice per column by one CU -- and never expected.
+__global__ __launch_bounds__(1024) void k_sytrd_takeover(ResArgs g) {
+  __shared__ double vs[kResMaxM], wsv[kResMaxM], sh[16];
+  const int m = g.m, n = g.L.n, tid = threadIdx.x;
+  double* Aw = g.a + (size_t)blockIdx.x * g.stride_a;
+  double* A = Aw + (size_t)g.off * n + g.off;
+  double* tri = g.tri + (size_t)blockIdx.x * g.L.slab;
+  const int* ctl = reinterpret_cast<const int*>(tri + g.L.rctl);
+  const bool lost = ctl[2] == 1;
+  if (ctl[0] == 1 && !lost) return;
+  if (lost && !g.full) {
+    if (tid == 0) atomicMax(g.status + 1, 1ull);
+    return;
+  }
+  if (tid == 0) atomicAdd(g.status + 7, 1ull);
+  const double f = tri[g.L.hscale + 2];
+  const bool bad = *reinterpret_cast<const unsigned long long*>(tri + g.L.hscale + 3) != 0ull;
+  for (size_t idx = tid; idx < (size_t)m * m; idx += 1024) {
+    const int j = (int)(idx / m), i = (int)(idx - (size_t)j * m);    // row i, column j
+    if (i <= j) continue;
+    if (lost) {   // lower <- upper (g.off = 0); the scaling pass has seen the upper entries with (row | 1) >= column only
+      const double x = bad ? 0.0 : A[(size_t)i * n + j] * (((j | 1) >= i || f == 1.0) ? 1.0 : f);
+      A[(size_t)j * n + i] = x;
+      A[(size_t)i * n + j] = x;
+    } else {
+      A[(size_t)i * n + j] = A[(size_t)j * n + i];
+    }
+  }
+  __syncthreads();
+  double* d_out = tri + g.L.d + g.off;
+  double* e_out = tri + g.L.e + g.off;
+  double* tau_out = tri + g.L.tau + g.off;
+  for (int c = 0; c <= m - 3; ++c) {
+    double np = 0.0;
+    for (int j = c + 2 + tid; j < m; j += 1024) { const double x = A[(size_t)c * n + j]; np += x * x; }
+    const double xn2 = block_sum_any(np, sh);
+    const HH h = householder(A[(size_t)c * n + c + 1], xn2);
+    for (int j = c + 1 + tid; j < m; j += 1024) {
+      const double x = j == c + 1 ? 1.0 : h.scale * A[(size_t)c * n + j];
+      vs[j] = x;
+    }
+    __syncthreads();
+    for (int j = c + 1 + tid; j < m; j += 1024) A[(size_t)c * n + j] = vs[j];
+    if (tid == 0) { d_out[c] = A[(size_t)c * n + c]; e_out[c] = h.beta; tau_out[c] = h.tau; }
+    if (h.tau != 0.0) {   // (block-uniform)
+      double dp = 0.0;
+      for (int i = c + 1 + tid; i < m; i += 1024) {
+        double y = 0.0;
+        for (int j = c + 1; j < m; ++j) y += A[(size_t)j * n + i] * vs[j];
+        y *= h.tau;
+        wsv[i] = y;
+        dp += y * vs[i];
+      }
+      const double alpha2 = -0.5 * h.tau * block_sum_any(dp, sh);
+      for (int i = c + 1 + tid; i < m; i += 1024) wsv[i] += alpha2 * vs[i];
+      __syncthreads();
+      for (int i = c + 1 + tid; i < m; i += 1024) {
+        const double vi = vs[i], wi = wsv[i];
+        for (int j = c + 1; j < m; ++j) A[(size_t)j * n + i] -= vi * wsv[j] + wi * vs[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    d_out[m - 2] = A[(size_t)(m - 2) * n + m - 2];
+    e_out[m - 2] = A[(size_t)(m - 2) * n + m - 1];
+    tau_out[m - 2] = 0.0;
+    d_out[m - 1] = A[(size_t)(m - 1) * n + m - 1];
+  }
+}
+
 }  // namespace
 
 int mirror_lower_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch) {
@@ -552,11 +950,79 @@ int unscale_values_batched(sc_ctx* ctx, double* d_w, long long stride_w, int m, 
 }
 
 
+// Whether (and from which column) k_sytrd_resident takes the reduction of this solve: one matrix (a batch is better
+// served by launches that all its matrices share), the trailing matrix from the first panel boundary at which its order
+// is <= 2048 -- the whole matrix for n <= 2048.  SPRINGCRAFT_RESIDENT = 0 switches it off; SPRINGCRAFT_RESIDENT_WGS = the
+// workgroups (a power of two; at least order / 8, at most the CUs of the device).
+struct ResPlan {
+  int off, m, P, logP, Q;
+  size_t lds;
+};
+static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
+  static const int env_mode = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT"); return e ? atoi(e) : -1; }();
+  static const int env_wgs = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_WGS"); return e ? atoi(e) : 0; }();
+  const int mode = ctx->resident_mode >= 0 ? ctx->resident_mode : env_mode;
+  if (mode == 0 || ctx->resident_ok == 0 || batch != 1 || n < 128) return false;
+  ResPlan R{};
+  R.off = n > kResMaxM ? (n - kResMaxM + nb - 1) / nb * nb : 0;
+  R.m = n - R.off;
+  if (R.m < 128) return false;
+  int P = 32, lp = 5;
+  while ((R.m + P - 1) / P > kResR) { P *= 2; ++lp; }
+  const int want = ctx->resident_wgs > 0 ? ctx->resident_wgs : (env_wgs > 0 ? env_wgs : 0);
+  while (P < want && 2 * P <= 256) { P *= 2; ++lp; }
+  if (P > (ctx->num_cus > 0 ? ctx->num_cus : 256)) return false;
+  R.P = P;
+  R.logP = lp;
+  const int qn = (R.m + 255) / 256;
+  R.Q = qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8));
+  const int ldr = (R.m + 63) & ~63, rmax = (R.m - 1) / P + 1;
+  R.lds = sizeof(double) * ((size_t)rmax * ldr + kResSmall);
+  *out = R;
+  return true;
+}
+
+template <int Q>
+static int launch_resident_q(sc_ctx* ctx, const ResArgs& g, const ResPlan& R, int batch) {
+  if (!sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_sytrd_resident<Q>), 160 * 1024)) return 1;
+  hipLaunchKernelGGL(k_sytrd_resident<Q>, dim3((unsigned)R.P, (unsigned)batch), dim3(256), R.lds, ctx->stream, g);
+  return SC_OK;
+}
+
+// SC_OK: enqueued (with its take-over); 1: not available on this device (the caller goes on with the launches per column)
+static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int batch, double* d_ws, const TriLayout& L,
+                           const ResPlan& R) {
+  hipStream_t st = ctx->stream;
+  ResArgs g{};
+  g.a = d_a; g.stride_a = stride_a; g.tri = d_ws; g.L = L;
+  g.off = R.off; g.m = R.m; g.P = R.P; g.logP = R.logP;
+  g.full = R.off == 0 ? 1 : 0;
+  g.hook = ctx->resident_hook;
+  g.status = ctx->d_status;
+  for (int b = 0; b < batch; ++b)
+    SC_HIP(ctx, hipMemsetAsync(d_ws + (size_t)b * L.slab + L.rctl, 0xFF, tri_resident_bytes(L.n), st));
+  int rc = 1;
+  switch (R.Q) {
+    case 1: rc = launch_resident_q<1>(ctx, g, R, batch); break;
+    case 2: rc = launch_resident_q<2>(ctx, g, R, batch); break;
+    case 4: rc = launch_resident_q<4>(ctx, g, R, batch); break;
+    case 6: rc = launch_resident_q<6>(ctx, g, R, batch); break;
+    default: rc = launch_resident_q<8>(ctx, g, R, batch); break;
+  }
+  if (rc != SC_OK) return rc;
+  hipLaunchKernelGGL(k_sytrd_takeover, dim3((unsigned)batch), dim3(1024), 0, st, g);
+  SC_HIP(ctx, hipGetLastError());
+  ++ctx->cnt_resident_launches;
+  return SC_OK;
+}
+
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv,
                     float* ms_syr2k) {
   hipStream_t st = ctx->stream;
   const int nb = L.nb;
+  ResPlan RP{};
+  bool use_res = resident_plan(ctx, n, batch, nb, &RP);
   // persistent SYMV grid: 4 resident blocks per CU (LDS-limited), shared by the matrices of the batch
   const int symv_blocks = 4 * (ctx->num_cus > 0 ? ctx->num_cus : 256);
   ScopedEvents<4> ev;
@@ -568,6 +1034,18 @@ int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int bat
   }
   int panel = 0;
   for (int j0 = 0; j0 < n; j0 += nb, ++panel) {
+    if (use_res && j0 == RP.off) {
+      PhaseTimer t_res(ctx, "resident_tridiag", st);
+      t_res.start();
+      const int rc = launch_resident(ctx, d_a, stride_a, batch, d_ws, L, RP);
+      t_res.stop();
+      if (rc == SC_OK) {
+        t_res.finish();
+        break;
+      }
+      if (rc != 1) return rc;
+      use_res = false;   // (the LDS size was refused: the launches per column)
+    }
     const int pend = j0 + nb < n ? j0 + nb : n;
     hipLaunchKernelGGL(k_zero_panels, dim3(64, (unsigned)batch), dim3(256), 0, st, d_ws, L);
     for (int c = j0; c < pend; ++c) {
