@@ -123,6 +123,11 @@ int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel);
  * workgroups: 0 = by size, else a power of two (SPRINGCRAFT_RESIDENT_WGS).  Counters "resident_launches" /
  * "resident_takeovers".  tests/test_eigh_gpu.py */
 int sc_dbg_set_resident(sc_ctx* ctx, int mode, int hook, int workgroups);
+/* Library built with -DRES_STAMPS (else returns 1): cycles workgroup 0 of k_sytrd_resident spent in the segments of a
+ * step -- [0] publish + poll of the records, [1] w~.v and the next column, [2] its norm, the next reflector and its
+ * stores, [3] the pass over the own rows, [5] the sums of y --, [7] = steps; summed since the last call.
+ * tools/resident_check.py --stamps */
+int sc_dbg_resident_stamps(unsigned long long* out8);
 
 #ifdef __cplusplus
 }

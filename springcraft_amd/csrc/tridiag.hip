@@ -572,9 +572,13 @@ struct ResArgs {
   int P, logP;            // workgroups per matrix (a power of two)
   int full;               // both triangles of the trailing matrix hold it (off = 0: straight after prepare_matrix_batched)
   int hook;               // tests: 1 = the roll call fails, 2 + c = the exchange of step c fails
+  int delay;              // pauses of 64 cycles between a step's publication and its first poll
   unsigned long long* status;
 };
 
+__device__ __forceinline__ double res_pair_raw(int lo, int hi) {
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
 template <int CTRL>
 __device__ __forceinline__ double res_dpp(double x) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -607,6 +611,27 @@ __device__ __forceinline__ double res_reduce8(const double (&v)[8]) {
   r += __shfl_xor(r, 32);
   return r;
 }
+// sum over the 64 lanes on the vector ALU alone (row_shr 1 2 4 8 inside the rows of 16, row_bcast 15 / 31 across them):
+// the total is in LANE 63 only.  (wave_sum above goes through the LDS crossbar: twelve ds_bpermute in a row.)
+__device__ __forceinline__ double res_wave_sum63(double x) {
+  x += res_dpp<0x111>(x);
+  x += res_dpp<0x112>(x);
+  x += res_dpp<0x114>(x);
+  x += res_dpp<0x118>(x);
+  {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x142, 0xa, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x142, 0xa, 0xf, false);
+    x += res_pair_raw(lo, hi);
+  }
+  {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x143, 0xc, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x143, 0xc, 0xf, false);
+    x += res_pair_raw(lo, hi);
+  }
+  return x;
+}
 __device__ __forceinline__ double res_pair(int lo, int hi) {
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
@@ -616,13 +641,30 @@ __device__ __forceinline__ void res_store(v4i* p, double x, double y) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
 }
 
+// Diagnostic build (-DRES_STAMPS): cycles (s_memtime) that thread 0 of workgroup 0 spends between six points of a step,
+// summed over the steps of a launch and added to g_res_stamps (sc_dbg_resident_stamps, tools/resident_check.py --stamps);
+// nothing of it in the normal build.
+#ifdef RES_STAMPS
+__device__ unsigned long long g_res_stamps[8];
+#define RES_STAMP(i)                                                                        \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    st_acc[i] += t_ - st_last;                                                              \
+    st_last = t_;                                                                           \
+  } while (0)
+#else
+#define RES_STAMP(i)
+#endif
+
 template <int Q>
 __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int m = g.m, lp = g.logP, P = g.P, n = g.L.n;
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int LDr = (m + 63) & ~63;
+  const int LDr = (m + 63) & ~63;                           // row stride in LDS
+  const int RL = LDr;                                       // records of one buffer
   const int R = k < m ? ((m - 1 - k) >> lp) + 1 : 0;        // own rows k, k + P, ...
   const int Rmax = ((m - 1) >> lp) + 1;
   double* Aw = g.a + (size_t)blockIdx.y * g.stride_a;
@@ -701,14 +743,20 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   double* const e_out = tri + g.L.e + g.off;
   double* const tau_out = tri + g.L.tau + g.off;
 
+#ifdef RES_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
   for (int c = -1; c <= m - 3; ++c) {
+    RES_STAMP(5);                                                // [5] y of the own rows summed
     if (c >= 0) {
-      v4i* rb = rec + (size_t)(c % 3) * LDr;
+      v4i* rb = rec + (size_t)(c % 3) * RL;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the emptying store of the previous step, see above)
       if (g.hook == 2 + c && k == 0 && tid == 0) atomicExch(&ctl[2], 1);
       if (tid < R && myr > c) res_store(rb + myr, tau * yown, rows[(size_t)tid * LDr + c + 1]);
-      // ---- poll the records of the rows j > c (all loads of a round in flight together; unconditional, a lane without
-      // a record of its own re-reads a neighbour's: a predicated load would let the compiler touch the register early)
+      // ---- poll the records of the rows j > c (all loads of a round in flight together; unconditional: a predicated
+      // load would let the compiler touch the register early.  A lane without a record of its own reads record c + 1:
+      // a record per wave for them, spread over the channels, measured no better -- 12.8 vs 12.6 ms at n = 1536)
       bool need[Q];
       const v4i* ptr[Q];
 #pragma unroll
@@ -717,6 +765,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         need[q] = j > c && j < m;
         ptr[q] = rb + (need[q] ? j : c + 1);
       }
+      for (int dly = 0; dly < g.delay; ++dly) __builtin_amdgcn_s_sleep(1);
       v4i r4[Q];
       long spins = 0;
       bool lost = false;
@@ -731,10 +780,12 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         if constexpr (Q == 8)
           asm volatile("s_waitcnt vmcnt(0)"
                        : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5]), "+v"(r4[6]), "+v"(r4[7])::"memory");
-        bool fresh = true;
+        // (a record that has arrived is read again in the rounds that wait for the others: pointing those loads at one
+        // record instead made the rounds slower, 14.2 -> 17.4 ms at n = 1536)
+        bool all = true;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) fresh = fresh && ((r4[q].x & r4[q].y) != -1);   // (a lane without a record reads a needed one)
-        if (__all(fresh)) break;
+        for (int q = 0; q < Q; ++q) all = all && ((r4[q].x & r4[q].y) != -1);   // (a lane without a record reads a needed one)
+        if (__all(all)) break;
         ++spins;
         if ((spins & 63) == 0 && __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { lost = true; break; }
         if (spins > (1L << 22)) {
@@ -743,9 +794,10 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
           break;
         }
       }
+      RES_STAMP(0);                                              // [0] publish + poll
       if (lost && lane == 0) s_flag[1] = 1;
       // the buffer of step c - 1 is free: every workgroup has published step c, so it has read step c - 1
-      if (tid < R && myr > c) res_store(rec + (size_t)((c + 2) % 3) * LDr + myr, res_pair(-1, -1), res_pair(-1, -1));
+      if (tid < R && myr > c) res_store(rec + (size_t)((c + 2) % 3) * RL + myr, res_pair(-1, -1), res_pair(-1, -1));
       double dp = 0.0;
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
@@ -755,8 +807,8 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         dp += w[q] * v[q];
         if (j == c + 1) bc[0] = w[q];
       }
-      dp = wave_sum(dp);
-      if (lane == 0) red[wave] = dp;
+      dp = res_wave_sum63(dp);
+      if (lane == 63) red[wave] = dp;
       lds_barrier();
       if (s_flag[1]) return;
       const double alpha2 = -0.5 * tau * ((red[0] + red[1]) + (red[2] + red[3]));
@@ -769,6 +821,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         }
       }
     }
+    RES_STAMP(1);                                                // [1] w~.v, w, a
     // ---- column c + 1 of the updated matrix is a[c+1 ..]: its diagonal entry, the pivot a[c+2], the norm below it
     double np = 0.0;
 #pragma unroll
@@ -783,8 +836,8 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         wrow[dj >> lp] = w[q];
       }
     }
-    np = wave_sum(np);
-    if (lane == 0) red[4 + wave] = np;
+    np = res_wave_sum63(np);
+    if (lane == 63) red[4 + wave] = np;
     lds_barrier();
     const double xn2 = (red[4] + red[5]) + (red[6] + red[7]);
     const HH h = householder(bc[1], xn2);
@@ -807,6 +860,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         tau_out[c + 1] = h.tau;
       }
     }
+    RES_STAMP(2);                                                // [2] norm, next reflector, its stores
     // ---- own rows >= c + 2, columns >= c + 2: A -= v w^T + w v^T, y = A vn
     double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -826,6 +880,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         }
       }
     }
+    RES_STAMP(3);                                                // [3] the pass over the own rows
     const double ys = res_reduce8(yp);
     if (lane < 8) red8[wave * 8 + res_reduce8_index(lane)] = ys;
     lds_barrier();
@@ -834,6 +889,12 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
     for (int q = 0; q < Q; ++q) v[q] = vn[q];
     tau = h.tau;
   }
+#ifdef RES_STAMPS
+  if (k == 0 && tid == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_res_stamps[i], st_acc[i]);
+    atomicAdd(&g_res_stamps[7], (unsigned long long)(m - 1));
+  }
+#endif
   // the last diagonal entry: with the row's owner, written by the thread that reads it here
   {
     const int jl = m - 1, dj = jl - k;
@@ -998,6 +1059,10 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
   g.off = R.off; g.m = R.m; g.P = R.P; g.logP = R.logP;
   g.full = R.off == 0 ? 1 : 0;
   g.hook = ctx->resident_hook;
+  // (the first poll a microsecond or so after the publication: polls that come back empty slow the stores they wait
+  // for -- all workgroups read all records --; n = 1536: 14.3 ms without the pause, 11.7 with 24 x 64 cycles, 13.8 with 64)
+  static const int env_delay = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_DELAY"); return e ? atoi(e) : 24; }();
+  g.delay = env_delay;
   g.status = ctx->d_status;
   for (int b = 0; b < batch; ++b)
     SC_HIP(ctx, hipMemsetAsync(d_ws + (size_t)b * L.slab + L.rctl, 0xFF, tri_resident_bytes(L.n), st));
@@ -1014,6 +1079,19 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
   SC_HIP(ctx, hipGetLastError());
   ++ctx->cnt_resident_launches;
   return SC_OK;
+}
+
+// ---- diagnostic build only (-DRES_STAMPS, else returns 1): out8[0..5] = cycles of workgroup 0 in the six segments of a
+// step of k_sytrd_resident (see RES_STAMP), out8[7] = steps; summed since the last call, reset by it
+extern "C" int sc_dbg_resident_stamps(unsigned long long* out8) {
+#ifdef RES_STAMPS
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_res_stamps), 64) != hipSuccess) return 5;
+  const unsigned long long z[8] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_res_stamps), z, 64) == hipSuccess ? 0 : 5;
+#else
+  (void)out8;
+  return 1;
+#endif
 }
 
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,

@@ -17,6 +17,7 @@ L = _hip.lib()
 ctx = _hip.context()
 L.sc_dbg_set_resident.restype = C.c_int
 L.sc_dbg_set_resident.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+L.sc_last_eigh_phase_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
 
 
 def counter(name):
@@ -59,6 +60,39 @@ def main():
             (w, v), t = run(a, 1, wgs=wgs, reps=5)
             print(f"n={n} workgroups>={wgs}: {t * 1e3:.2f} ms, launches {counter('resident_launches') - l0}, "
                   f"errors {errors(a, w, v)}", flush=True)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--stamps":
+        # (library built with -DRES_STAMPS: tools/build_res_stamps_lib.sh, SPRINGCRAFT_HIP_LIB)
+        out = (C.c_ulonglong * 8)()
+        for n in [int(x) for x in sys.argv[2:]]:
+            a = rs.randn(n, n)
+            a = a + a.T
+            run(a, 1, reps=2)
+            L.sc_dbg_resident_stamps(out)
+            (w, v), t = run(a, 1, reps=1)
+            rc = L.sc_dbg_resident_stamps(out)
+            steps = max(out[7], 1)
+            names = ["publish+poll", "w~.v, w, a", "norm, reflector, stores", "pass", "-", "y sums"]
+            print(f"n={n}: rc {rc}, {t * 1e3:.2f} ms, steps {out[7]}, cycles (100 MHz) per step: "
+                  + ", ".join(f"{names[i]} {out[i] / steps:.1f}" for i in (0, 1, 2, 3, 5))
+                  + f" | total {sum(out[i] for i in range(6)) / steps:.1f} = {sum(out[i] for i in range(6)) / 100e3:.2f} ms", flush=True)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--phases":
+        t6 = (C.c_double * 6)()
+        ms = C.c_double(0)
+        for n in [int(x) for x in sys.argv[2:]]:
+            a = rs.randn(n, n)
+            a = a + a.T
+            for mode in (0, 1):
+                run(a, mode, reps=2)
+                L.sc_ctx_set_profiling(ctx.handle, 1)
+                (w, v), t = run(a, mode, reps=1)
+                L.sc_ctx_set_profiling(ctx.handle, 0)
+                L.sc_last_eigh_timings(ctx.handle, t6)
+                rc = L.sc_last_eigh_phase_ms(ctx.handle, b"resident_tridiag", C.byref(ms))
+                print(f"n={n} resident={mode}: profiled solve {t * 1e3:.2f} ms: tridiagonalisation {t6[0]:.2f} "
+                      f"(resident kernel {ms.value if rc == 0 else 0.0:.2f}), D&C {t6[1]:.2f}, back-transformation {t6[2]:.2f} ms",
+                      flush=True)
         return
     sizes = [int(s) for s in sys.argv[1:]] or [128, 300, 900, 1536, 2048]
     for n in sizes:
