@@ -641,6 +641,36 @@ __device__ __forceinline__ void res_store(v4i* p, double x, double y) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
 }
 
+// The pass of a step over NR own rows (the live ones, consecutive in LDS from `row`): A -= v w^T + w v^T and the products
+// with the next reflector, chunk of 256 columns by chunk.  No test per element -- v, w and vn are zero at the columns that
+// are done (but for column c + 1, whose entries nobody reads again) and in the padding of the rows --, so the NR reads of a
+// chunk are in flight together: with a test per element every read waited for the LDS on its own, 70 cycles per element.
+template <int Q, int NR>
+__device__ __forceinline__ void res_pass(double* row, const double* vr_l, const double* wr_l, int q0, int qn,
+                                         const double (&v)[Q], const double (&w)[Q], const double (&vn)[Q], double (&acc)[8]) {
+  constexpr int LDr = 256 * Q;
+  double vr[NR], wr[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    vr[u] = vr_l[u];
+    wr[u] = wr_l[u];
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (q >= q0 && q < qn) {   // (uniform)
+      double x[NR];
+#pragma unroll
+      for (int u = 0; u < NR; ++u) x[u] = row[u * LDr + 256 * q];
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        x[u] -= vr[u] * w[q] + wr[u] * v[q];
+        row[u * LDr + 256 * q] = x[u];
+        acc[u] += x[u] * vn[q];
+      }
+    }
+  }
+}
+
 // Diagnostic build (-DRES_STAMPS): cycles (s_memtime) that thread 0 of workgroup 0 spends between six points of a step,
 // summed over the steps of a launch and added to g_res_stamps (sc_dbg_resident_stamps, tools/resident_check.py --stamps);
 // nothing of it in the normal build.
@@ -663,8 +693,9 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   const int m = g.m, lp = g.logP, P = g.P, n = g.L.n;
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int LDr = (m + 63) & ~63;                           // row stride in LDS
-  const int RL = LDr;                                       // records of one buffer
+  constexpr int LDr = 256 * Q;                              // row stride in LDS
+  const int RL = (m + 63) & ~63;                            // records of one buffer
+  const int Qn = (m + 255) >> 8;                            // chunks of 256 columns with entries
   const int R = k < m ? ((m - 1 - k) >> lp) + 1 : 0;        // own rows k, k + P, ...
   const int Rmax = ((m - 1) >> lp) + 1;
   double* Aw = g.a + (size_t)blockIdx.y * g.stride_a;
@@ -739,6 +770,12 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
 
   double tau = 0.0, yown = 0.0;
   const int myr = k + (tid << lp);      // the row thread tid < R publishes
+  unsigned ownmask = 0;                 // bit q: entry tid + 256 q of a vector belongs to an own row
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int dj = tid + 256 * q - k;
+    if (dj >= 0 && (dj & (P - 1)) == 0 && tid + 256 * q < m) ownmask |= 1u << q;
+  }
   double* const d_out = tri + g.L.d + g.off;
   double* const e_out = tri + g.L.e + g.off;
   double* const tau_out = tri + g.L.tau + g.off;
@@ -801,11 +838,14 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       double dp = 0.0;
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const int j = tid + 256 * q;
         w[q] = need[q] ? res_pair(r4[q].x, r4[q].y) : 0.0;     // w~ = tau y
         a[q] = need[q] ? res_pair(r4[q].z, r4[q].w) : 0.0;     // A[j, c+1] before this step's update
         dp += w[q] * v[q];
-        if (j == c + 1) bc[0] = w[q];
+      }
+      if (tid == ((c + 1) & 255)) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (q == ((c + 1) >> 8)) bc[0] = w[q];
       }
       dp = res_wave_sum63(dp);
       if (lane == 63) red[wave] = dp;
@@ -827,14 +867,26 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int j = tid + 256 * q;
-      if (j >= c + 3 && j < m) np += a[q] * a[q];
-      if (j == c + 2) bc[1] = a[q];
-      if (j == c + 1) bc[2] = a[q];
-      const int dj = j - k;
-      if (dj >= 0 && (dj & (P - 1)) == 0 && j < m) {           // an own row: this step's v and w at it, for the update below
-        vrow[dj >> lp] = v[q];
-        wrow[dj >> lp] = w[q];
-      }
+      if (j >= c + 3) np += a[q] * a[q];                        // (a is zero from row m on)
+    }
+    if (tid == ((c + 2) & 255)) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (q == ((c + 2) >> 8)) bc[1] = a[q];
+    }
+    if (tid == ((c + 1) & 255)) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (q == ((c + 1) >> 8)) bc[2] = a[q];
+    }
+    if (ownmask) {                                              // own rows: this step's v and w at them, for the update below
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (ownmask >> q & 1) {
+          const int i = (tid + 256 * q - k) >> lp;
+          vrow[i] = v[q];
+          wrow[i] = w[q];
+        }
     }
     np = res_wave_sum63(np);
     if (lane == 63) red[4 + wave] = np;
@@ -844,7 +896,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int j = tid + 256 * q;
-      vn[q] = (j > c + 2 && j < m) ? h.scale * a[q] : (j == c + 2 ? 1.0 : 0.0);
+      vn[q] = j > c + 2 ? h.scale * a[q] : (j == c + 2 ? 1.0 : 0.0);
     }
     if (k == ((c + 1) & (P - 1))) {
       if (c + 1 <= m - 3) {
@@ -862,29 +914,31 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
     }
     RES_STAMP(2);                                                // [2] norm, next reflector, its stores
     // ---- own rows >= c + 2, columns >= c + 2: A -= v w^T + w v^T, y = A vn
-    double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < kResR; ++i) {
-      if (i < R && k + (i << lp) >= c + 2) {
-        const double vr = vrow[i], wr = wrow[i];
-        double* row = rows + (size_t)i * LDr;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const int j = tid + 256 * q;
-          if (j >= c + 2 && j < m) {
-            double x = row[j];
-            x -= vr * w[q] + wr * v[q];
-            row[j] = x;
-            yp[i] += x * vn[q];
-          }
-        }
+    double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // [u]: own row i0 + u
+    const int i0 = c + 2 > k ? (c + 2 - k + P - 1) >> lp : 0;   // the own rows from i0 on are live
+    {
+      double* row = rows + (size_t)i0 * LDr + tid;
+      const int q0 = (c + 2) >> 8;
+      switch (R - i0) {
+        case 1: res_pass<Q, 1>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 2: res_pass<Q, 2>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 3: res_pass<Q, 3>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 4: res_pass<Q, 4>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 5: res_pass<Q, 5>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 6: res_pass<Q, 6>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 7: res_pass<Q, 7>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        case 8: res_pass<Q, 8>(row, vrow + i0, wrow + i0, q0, Qn, v, w, vn, yp); break;
+        default: break;   // (no live row left)
       }
     }
     RES_STAMP(3);                                                // [3] the pass over the own rows
     const double ys = res_reduce8(yp);
     if (lane < 8) red8[wave * 8 + res_reduce8_index(lane)] = ys;
     lds_barrier();
-    if (tid < 8) yown = (red8[tid] + red8[8 + tid]) + (red8[16 + tid] + red8[24 + tid]);
+    if (tid < 8) {
+      const int u = tid - i0;
+      yown = (u >= 0 && tid < R) ? (red8[u] + red8[8 + u]) + (red8[16 + u] + red8[24 + u]) : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) v[q] = vn[q];
     tau = h.tau;
@@ -1037,7 +1091,7 @@ static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
   R.logP = lp;
   const int qn = (R.m + 255) / 256;
   R.Q = qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8));
-  const int ldr = (R.m + 63) & ~63, rmax = (R.m - 1) / P + 1;
+  const int ldr = 256 * R.Q, rmax = (R.m - 1) / P + 1;
   R.lds = sizeof(double) * ((size_t)rmax * ldr + kResSmall);
   *out = R;
   return true;

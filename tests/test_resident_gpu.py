@@ -1,0 +1,144 @@
+"""
+GPU tests of the one-launch tridiagonalisation of ONE matrix (k_sytrd_resident, tridiag.hip: the rows of the matrix stay
+in LDS, one exchange between the workgroups per column) -- the path the reference's own call takes, one structure at a
+time (anm.py:150-167 -> nma.py:61) -- against LAPACK on the same matrix, through the Python API -> C ABI.  Gates as in
+test_eigh_gpu.py (the solver reaches ~1e-14; pinned at 1e-11).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import check_eigenvectors
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def res():
+    """(package, library, context, setter): the debug entry is reset to the default rule afterwards."""
+    import os
+
+    import springcraft_amd as sc
+    from springcraft_amd import _hip
+
+    if os.environ.get("SPRINGCRAFT_RESIDENT") == "0":
+        pytest.skip("SPRINGCRAFT_RESIDENT=0: the kernel under test is switched off")
+    L = _hip.lib()
+    ctx = _hip.context()
+    L.sc_dbg_set_resident.restype = C.c_int
+    L.sc_dbg_set_resident.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+    def counter(name):
+        v = C.c_int64(0)
+        ctx.check(L.sc_ctx_get_counter(ctx.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def set_(mode, hook=0, wgs=0):
+        ctx.check(L.sc_dbg_set_resident(ctx.handle, mode, hook, wgs))
+
+    ctx.set_two_stage(False)
+    try:
+        yield sc, counter, set_
+    finally:
+        set_(-1)
+        ctx.set_two_stage(None)
+
+
+def sym(seed, n):
+    a = np.random.RandomState(seed).randn(n, n)
+    return a + a.T
+
+
+def check(sc, a, tol=1e-11):
+    w, v = sc.nma.eigh(a)
+    w_ref = np.linalg.eigvalsh(a)
+    assert np.abs(w - w_ref).max() <= tol * max(np.abs(w_ref).max(), 1e-300)
+    check_eigenvectors(np.tril(a) + np.tril(a, -1).T, w, v, tol_res=tol, tol_orth=tol)
+    return w
+
+
+@pytest.mark.parametrize("n", [128, 129, 255, 300, 513, 1000, 1537, 2048])
+def test_whole_matrix_in_one_launch(res, n):
+    """Orders on both sides of every internal boundary: 256 columns per thread chunk, 8 rows per workgroup, odd orders,
+    the largest order that fits (2048); eigenvalues only and the partial spectrum take the same reduction."""
+    sc, counter, set_ = res
+    a = sym(n, n)
+    before = counter("resident_launches")
+    w = check(sc, a)
+    assert counter("resident_launches") == before + 1
+    w_only = sc.nma.eigh(a, eigenvectors=False)
+    assert np.abs(w_only - w).max() <= 1e-11 * np.abs(w).max()
+    ws, vs = sc.nma.eigh(a, subset_by_index=(3, 40))
+    assert np.abs(ws - w[3:41]).max() <= 1e-11 * np.abs(w).max()
+    assert counter("resident_launches") == before + 3 and counter("resident_takeovers") == 0
+    # same eigenvalues as the launches per column give
+    set_(0)
+    w_col = sc.nma.eigh(a, eigenvectors=False)
+    assert counter("resident_launches") == before + 3
+    assert np.abs(w_col - w).max() <= 1e-11 * np.abs(w).max()
+
+
+@pytest.mark.parametrize("wgs", [64, 128, 256])
+def test_workgroup_counts(res, wgs):
+    """The number of workgroups is a free parameter above order / 8: same results with 64, 128, 256 of them."""
+    sc, counter, set_ = res
+    a = sym(7, 400)
+    set_(1, 0, wgs)
+    check(sc, a)
+
+
+def test_trailing_matrix_of_a_larger_order(res):
+    """n = 2300: four panels by the launches per column, the trailing matrix of order 2044 (lower triangle only valid
+    behind the SYR2K updates) in one launch."""
+    sc, counter, set_ = res
+    a = sym(11, 2300)
+    before = counter("resident_launches")
+    check(sc, a)
+    assert counter("resident_launches") == before + 1
+
+
+def test_scaled_input_and_only_the_lower_triangle(res):
+    """A matrix that the solver rescales (largest entry 1e200: the scaling pass touches the lower triangle only, the rows
+    are then gathered from it) and junk in NumPy's upper triangle (UPLO = 'L')."""
+    sc, counter, set_ = res
+    a = sym(3, 500)
+    w_ref = np.linalg.eigvalsh(a)
+    w, v = sc.nma.eigh(a * 1e200)
+    assert np.all(np.isfinite(w)) and np.abs(w / 1e200 - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    junk = a.copy()
+    junk[np.triu_indices(500, 1)] = 1e3
+    junk[5, 400] = np.nan
+    w, v = sc.nma.eigh(junk)
+    assert np.abs(w - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+    check_eigenvectors(a, w, v, tol_res=1e-11, tol_orth=1e-11)
+
+
+@pytest.mark.parametrize("n,hook", [(300, 1), (300, 2 + 150), (700, 2 + 0), (2300, 1)])
+def test_take_over(res, n, hook):
+    """The take-over kernel behind every launch: a failed roll call (nothing stored yet; also for a trailing matrix) and
+    a wait lost in mid-run (the matrix is restored from its other triangle) still give LAPACK's eigenpairs; the event is
+    counted and the context keeps to the launches per column until the debug entry re-arms it."""
+    sc, counter, set_ = res
+    a = sym(n + hook, n)
+    set_(1, hook)
+    t0, l0 = counter("resident_takeovers"), counter("resident_launches")
+    check(sc, a)
+    assert counter("resident_takeovers") == t0 + 1 and counter("resident_launches") == l0 + 1
+    check(sc, a)         # (the hook is still set, but the context stays away from the kernel)
+    assert counter("resident_takeovers") == t0 + 1 and counter("resident_launches") == l0 + 1
+    set_(1, 0)           # the debug entry re-arms it
+    check(sc, a)
+    assert counter("resident_takeovers") == t0 + 1 and counter("resident_launches") == l0 + 2
+
+
+def test_lost_wait_in_a_trailing_matrix_fails_the_solve(res):
+    """A trailing matrix cannot be restarted (its upper triangle is stale): a wait lost in mid-run there surfaces as
+    LinAlgError through the deferred status, as a QL failure would; the next solve is clean."""
+    sc, counter, set_ = res
+    a = sym(13, 2300)
+    set_(1, 2 + 500)
+    with pytest.raises(np.linalg.LinAlgError):
+        sc.nma.eigh(a)
+    set_(1, 0)
+    check(sc, sym(14, 300))
