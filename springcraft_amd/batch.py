@@ -338,7 +338,8 @@ def _last_timings(ctx, L):
         out.update(two_stage=True, band_reduction_ms=t[3], bulge_chasing_ms=t[4], bt2_apply_ms=t[5])
     else:
         out.update(two_stage=False, symv_ms=t[3], syr2k_ms=t[4])
-    for name in ("panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update", "sturm", "stein", "cholqr"):
+    for name in ("resident_tridiag", "panel_qr", "symm", "syr2k", "dia_tfactor", "dc_gemm", "bt1_w", "bt1_update", "sturm",
+                 "stein", "cholqr"):
         ms = C.c_double(0.0)
         if L.sc_last_eigh_phase_ms(ctx.handle, name.encode(), C.byref(ms)) == 0 and name + "_ms" not in out:
             out[name + "_ms"] = ms.value

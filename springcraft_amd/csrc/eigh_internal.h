@@ -39,6 +39,9 @@ int unscale_values_batched(sc_ctx* ctx, double* d_w, long long stride_w, int m, 
 
 int tridiag_batched(sc_ctx* ctx, double* d_a, long long stride_a, int n, int batch, double* d_ws,
                     const TriLayout& L, const GemmDesc* d_syr2k_descs, float* ms_symv, float* ms_syr2k);
+// whether tridiag_batched hands the (trailing) matrix of a one-matrix solve to k_sytrd_resident on this context (ctx may
+// be null: the environment's answer)
+bool resident_enabled(const sc_ctx* ctx);
 
 // ---- divide & conquer ------------------------------------------------------------------------------
 struct DcNode {

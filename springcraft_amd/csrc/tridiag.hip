@@ -1073,11 +1073,14 @@ struct ResPlan {
   int off, m, P, logP, Q;
   size_t lds;
 };
-static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
+bool resident_enabled(const sc_ctx* ctx) {
   static const int env_mode = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT"); return e ? atoi(e) : -1; }();
+  const int mode = (ctx && ctx->resident_mode >= 0) ? ctx->resident_mode : env_mode;
+  return mode != 0 && !(ctx && ctx->resident_ok == 0);
+}
+static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
   static const int env_wgs = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_WGS"); return e ? atoi(e) : 0; }();
-  const int mode = ctx->resident_mode >= 0 ? ctx->resident_mode : env_mode;
-  if (mode == 0 || ctx->resident_ok == 0 || batch != 1 || n < 128) return false;
+  if (!resident_enabled(ctx) || batch != 1 || n < 128) return false;
   ResPlan R{};
   R.off = n > kResMaxM ? (n - kResMaxM + nb - 1) / nb * nb : 0;
   R.m = n - R.off;

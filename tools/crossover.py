@@ -19,7 +19,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / 3 * 1e3:.1f}")
 '''
-for n_atoms, B in ((4000, 1), (3000, 1), (2500, 1), (2000, 1), (2000, 2), (2000, 3), (2000, 4), (1500, 1), (1500, 2), (1000, 1), (1000, 4), (1000, 8), (1000, 16), (500, 8), (500, 16), (500, 32), (500, 64), (342, 64), (171, 256)):
+ROWS = ((4000, 1), (3000, 1), (2500, 1), (2000, 1), (2000, 2), (2000, 3), (2000, 4), (1500, 1), (1500, 2), (1000, 1), (1000, 4), (1000, 8), (1000, 16), (500, 8), (500, 16), (500, 32), (500, 64), (342, 64), (171, 256))
+if len(sys.argv) > 1 and sys.argv[1] == "--single":   # one structure at a time (round 6: the resident one-stage reduction)
+    ROWS = tuple((int(x), 1) for x in sys.argv[2:]) or ((683, 1), (1000, 1), (1200, 1), (1400, 1), (1500, 1), (1700, 1), (2000, 1), (2500, 1))
+for n_atoms, B in ROWS:
     row = []
     for two in (0, 1):
         r = subprocess.run([sys.executable, "-c", code, str(n_atoms), str(B), str(two)], capture_output=True, text=True, timeout=300)
