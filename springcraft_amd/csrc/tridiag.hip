@@ -560,8 +560,9 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 // launches; a trailing-matrix launch reports the failed solve through the status word).
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kResR = 8;                 // rows per workgroup at most
-constexpr int kResMaxM = 2048;           // order of the (trailing) matrix at most: 8 entries of a vector per thread
-constexpr int kResSmall = 96;            // doubles of LDS besides the rows
+constexpr int kResMaxLds = 2048;         // order of the (trailing) matrix at most with the rows in LDS: 8 rows of 8 x 256 entries
+constexpr int kResMaxM = 3072;           // ... with the rows in registers: 12 rows of 12 x 256 entries (256 workgroups)
+constexpr int kResSmall = 160;           // doubles of LDS besides the rows
 
 struct ResArgs {
   double* a;              // whole matrices, column-major, leading dimension L.n
@@ -687,7 +688,10 @@ __device__ unsigned long long g_res_stamps[8];
 #define RES_STAMP(i)
 #endif
 
-template <int Q>
+// RR = 0: the own rows in LDS (orders up to 2048).  RR > 0: in REGISTERS, RR rows at most (orders up to 3072 with P = 256:
+// thread t keeps the entries t, t + 256, ... of all own rows, <= 12 x 12 doubles of the 512 registers a thread of a
+// 256-thread workgroup may have; a pass touches only the thread's own entries, so LDS was never more than storage).
+template <int Q, int RR>
 __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int m = g.m, lp = g.logP, P = g.P, n = g.L.n;
@@ -703,13 +707,15 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   double* tri = g.tri + (size_t)blockIdx.y * g.L.slab;
   int* ctl = reinterpret_cast<int*>(tri + g.L.rctl);        // [0] -1 undecided / 1 go / 2 abort, [1] arrivals - 1, [2] 1 = a wait was lost
   v4i* rec = reinterpret_cast<v4i*>(tri + g.L.rrec);
-  double* rows = sm;                                         // [Rmax][LDr]
-  double* red = rows + (size_t)Rmax * LDr;                   // [4] [4] : partial sums of the two reductions
-  double* red8 = red + 8;                                    // [4][8]
-  double* bc = red8 + 32;                                    // [4]   values every thread needs
-  double* vrow = bc + 4;                                     // [8]   v_c, w_c at the own rows
-  double* wrow = vrow + 8;
-  int* s_flag = reinterpret_cast<int*>(wrow + 8);            // [0] go, [1] dead
+  double* rows = sm;                                         // [Rmax][LDr]  (RR = 0)
+  double* red = RR > 0 ? sm : rows + (size_t)Rmax * LDr;     // [4] [4] : partial sums of the two reductions
+  double* red8 = red + 8;                                    // [4][16]
+  double* bc = red8 + 64;                                    // [4]   values every thread needs
+  double* vrow = bc + 4;                                     // [16]  v_c, w_c at the own rows (RR > 0: pairs {v, w}, [16][2])
+  double* wrow = vrow + 16;
+  double* colbuf = wrow + 16;                                // [16]  RR > 0: the own rows' entries of the next column
+  int* s_flag = reinterpret_cast<int*>(colbuf + 16);         // [0] go, [1] dead
+  double xr[RR > 0 ? RR : 1][Q];                             // RR > 0: the own rows
 
   // ---- the own rows -> LDS.  Straight after prepare_matrix_batched both triangles hold the matrix (the mirror pass
   // copies, it does not move), so a row is contiguous in memory; the scaling pass touches the lower triangle only, and a
@@ -718,12 +724,26 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
     const double f = tri[g.L.hscale + 2];
     const bool bad = *reinterpret_cast<const unsigned long long*>(tri + g.L.hscale + 3) != 0ull;
     const bool full = g.full && f == 1.0 && !bad;
-    for (int i = 0; i < R; ++i) {
-      const int r = k + (i << lp);
-      for (int j = tid; j < LDr; j += 256) {
-        double x = 0.0;
-        if (j < m) x = (full || j >= r) ? A[(size_t)r * n + j] : A[(size_t)j * n + r];
-        rows[(size_t)i * LDr + j] = x;
+    if constexpr (RR > 0) {
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        const int r = k + (i << lp);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int j = tid + 256 * q;
+          double x = 0.0;
+          if (i < R && j < m) x = (full || j >= r) ? A[(size_t)r * n + j] : A[(size_t)j * n + r];
+          xr[i][q] = x;
+        }
+      }
+    } else {
+      for (int i = 0; i < R; ++i) {
+        const int r = k + (i << lp);
+        for (int j = tid; j < LDr; j += 256) {
+          double x = 0.0;
+          if (j < m) x = (full || j >= r) ? A[(size_t)r * n + j] : A[(size_t)j * n + r];
+          rows[(size_t)i * LDr + j] = x;
+        }
       }
     }
   }
@@ -790,10 +810,10 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       v4i* rb = rec + (size_t)(c % 3) * RL;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the emptying store of the previous step, see above)
       if (g.hook == 2 + c && k == 0 && tid == 0) atomicExch(&ctl[2], 1);
-      if (tid < R && myr > c) res_store(rb + myr, tau * yown, rows[(size_t)tid * LDr + c + 1]);
-      // ---- poll the records of the rows j > c (all loads of a round in flight together; unconditional: a predicated
-      // load would let the compiler touch the register early.  A lane without a record of its own reads record c + 1:
-      // a record per wave for them, spread over the channels, measured no better -- 12.8 vs 12.6 ms at n = 1536)
+      if (tid < R && myr > c) res_store(rb + myr, tau * yown, RR > 0 ? colbuf[tid] : rows[(size_t)tid * LDr + c + 1]);
+      // ---- poll the records of the rows j > c (all loads of a round in flight together; no predicate per lane: a
+      // predicated load would let the compiler touch the register early.  A lane without a record of its own reads record
+      // c + 1: a record per wave for them, spread over the channels, measured no better -- 12.8 vs 12.6 ms at n = 1536)
       bool need[Q];
       const v4i* ptr[Q];
 #pragma unroll
@@ -804,6 +824,8 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       }
       for (int dly = 0; dly < g.delay; ++dly) __builtin_amdgcn_s_sleep(1);
       v4i r4[Q];
+      // (no load at all for the chunks of 256 rows that are done, behind a uniform test: measured slower, 11.0 -> 12.6 ms
+      // at n = 1536)
       long spins = 0;
       bool lost = false;
       while (true) {
@@ -817,6 +839,14 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
         if constexpr (Q == 8)
           asm volatile("s_waitcnt vmcnt(0)"
                        : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5]), "+v"(r4[6]), "+v"(r4[7])::"memory");
+        if constexpr (Q == 10)
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5]), "+v"(r4[6]), "+v"(r4[7]),
+                         "+v"(r4[8]), "+v"(r4[9])::"memory");
+        if constexpr (Q == 12)
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(r4[5]), "+v"(r4[6]), "+v"(r4[7]),
+                         "+v"(r4[8]), "+v"(r4[9]), "+v"(r4[10]), "+v"(r4[11])::"memory");
         // (a record that has arrived is read again in the rounds that wait for the others: pointing those loads at one
         // record instead made the rounds slower, 14.2 -> 17.4 ms at n = 1536)
         bool all = true;
@@ -884,8 +914,13 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       for (int q = 0; q < Q; ++q)
         if (ownmask >> q & 1) {
           const int i = (tid + 256 * q - k) >> lp;
-          vrow[i] = v[q];
-          wrow[i] = w[q];
+          if constexpr (RR > 0) {
+            vrow[2 * i] = v[q];
+            vrow[2 * i + 1] = w[q];
+          } else {
+            vrow[i] = v[q];
+            wrow[i] = w[q];
+          }
         }
     }
     np = res_wave_sum63(np);
@@ -914,9 +949,47 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
     }
     RES_STAMP(2);                                                // [2] norm, next reflector, its stores
     // ---- own rows >= c + 2, columns >= c + 2: A -= v w^T + w v^T, y = A vn
-    double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // [u]: own row i0 + u
+    double yp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // [u]: own row i0 + u  (RR > 0: own row u)
+    double yp2[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // RR > 0: own row 8 + u
     const int i0 = c + 2 > k ? (c + 2 - k + P - 1) >> lp : 0;   // the own rows from i0 on are live
-    {
+    if constexpr (RR > 0) {
+      const int q0 = (c + 2) >> 8;
+      double vr[RR], wr[RR];
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        vr[i] = vrow[2 * i];
+        wr[i] = vrow[2 * i + 1];
+      }
+      // (rows that are done are skipped; inside a live row only the lower half of the chunks is tested: v, w and vn are
+      // zero at the columns that are done, and a test per chunk cost more than the products it saved)
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        if (i >= i0 && i < R) {     // (uniform)
+          double acc = 0.0;
+          if (q0 < Q / 2) {
+#pragma unroll
+            for (int q = 0; q < Q / 2; ++q) {
+              xr[i][q] -= vr[i] * w[q] + wr[i] * v[q];
+              acc += xr[i][q] * vn[q];
+            }
+          }
+#pragma unroll
+          for (int q = Q / 2; q < Q; ++q) {
+            xr[i][q] -= vr[i] * w[q] + wr[i] * v[q];
+            acc += xr[i][q] * vn[q];
+          }
+          if (i < 8) yp[i & 7] = acc; else yp2[i & 7] = acc;
+        }
+      }
+      if (tid == ((c + 2) & 255)) {   // the own rows' entries of column c + 2: what the next step's records carry
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (q == q0) {
+#pragma unroll
+            for (int i = 0; i < RR; ++i) colbuf[i] = xr[i][q];
+          }
+      }
+    } else {
       double* row = rows + (size_t)i0 * LDr + tid;
       const int q0 = (c + 2) >> 8;
       switch (R - i0) {
@@ -932,12 +1005,22 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       }
     }
     RES_STAMP(3);                                                // [3] the pass over the own rows
-    const double ys = res_reduce8(yp);
-    if (lane < 8) red8[wave * 8 + res_reduce8_index(lane)] = ys;
-    lds_barrier();
-    if (tid < 8) {
-      const int u = tid - i0;
-      yown = (u >= 0 && tid < R) ? (red8[u] + red8[8 + u]) + (red8[16 + u] + red8[24 + u]) : 0.0;
+    if constexpr (RR > 0) {
+      const double ys = res_reduce8(yp), ys2 = res_reduce8(yp2);
+      if (lane < 8) {
+        red8[wave * 16 + res_reduce8_index(lane)] = ys;
+        red8[wave * 16 + 8 + res_reduce8_index(lane)] = ys2;
+      }
+      lds_barrier();
+      if (tid < 16) yown = tid < R ? (red8[tid] + red8[16 + tid]) + (red8[32 + tid] + red8[48 + tid]) : 0.0;
+    } else {
+      const double ys = res_reduce8(yp);
+      if (lane < 8) red8[wave * 8 + res_reduce8_index(lane)] = ys;
+      lds_barrier();
+      if (tid < 8) {
+        const int u = tid - i0;
+        yown = (u >= 0 && tid < R) ? (red8[u] + red8[8 + u]) + (red8[16 + u] + red8[24 + u]) : 0.0;
+      }
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) v[q] = vn[q];
@@ -952,7 +1035,17 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
   // the last diagonal entry: with the row's owner, written by the thread that reads it here
   {
     const int jl = m - 1, dj = jl - k;
-    if (dj >= 0 && (dj & (P - 1)) == 0 && tid == (jl & 255)) d_out[jl] = rows[(size_t)(dj >> lp) * LDr + jl];
+    if (dj >= 0 && (dj & (P - 1)) == 0 && tid == (jl & 255)) {
+      if constexpr (RR > 0) {
+#pragma unroll
+        for (int i = 0; i < RR; ++i)
+#pragma unroll
+          for (int q = 0; q < Q; ++q)
+            if (i == (dj >> lp) && q == (jl >> 8)) d_out[jl] = xr[i][q];
+      } else {
+        d_out[jl] = rows[(size_t)(dj >> lp) * LDr + jl];
+      }
+    }
   }
 }
 
@@ -962,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
 // Then LAPACK's dsytd2 from memory on the full symmetric matrix (the other triangle is filled in first), a thread per row:
 // slow -- the matrix is streamed twice per column by one CU -- and never expected.
 __global__ __launch_bounds__(1024) void k_sytrd_takeover(ResArgs g) {
-  __shared__ double vs[kResMaxM], wsv[kResMaxM], sh[16];
+  __shared__ double vs[kResMaxM], wsv[kResMaxM], sh[16];   // (48 KB)
   const int m = g.m, n = g.L.n, tid = threadIdx.x;
   double* Aw = g.a + (size_t)blockIdx.x * g.stride_a;
   double* A = Aw + (size_t)g.off * n + g.off;
@@ -1071,6 +1164,7 @@ int unscale_values_batched(sc_ctx* ctx, double* d_w, long long stride_w, int m, 
 // workgroups (a power of two; at least order / 8, at most the CUs of the device).
 struct ResPlan {
   int off, m, P, logP, Q;
+  bool reg;       // rows in registers
   size_t lds;
 };
 bool resident_enabled(const sc_ctx* ctx) {
@@ -1082,28 +1176,33 @@ static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
   static const int env_wgs = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_WGS"); return e ? atoi(e) : 0; }();
   if (!resident_enabled(ctx) || batch != 1 || n < 128) return false;
   ResPlan R{};
-  R.off = n > kResMaxM ? (n - kResMaxM + nb - 1) / nb * nb : 0;
+  static const int env_max = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_MAX"); return e ? atoi(e) : kResMaxM; }();
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  int max_m = cus >= 256 ? kResMaxM : kResMaxLds;     // (the register form needs 256 workgroups)
+  if (env_max >= 128) max_m = std::min(max_m, env_max);
+  R.off = n > max_m ? (n - max_m + nb - 1) / nb * nb : 0;
   R.m = n - R.off;
   if (R.m < 128) return false;
+  R.reg = R.m > kResMaxLds;
   int P = 32, lp = 5;
-  while ((R.m + P - 1) / P > kResR) { P *= 2; ++lp; }
+  while ((R.m + P - 1) / P > (R.reg ? 12 : kResR)) { P *= 2; ++lp; }
   const int want = ctx->resident_wgs > 0 ? ctx->resident_wgs : (env_wgs > 0 ? env_wgs : 0);
   while (P < want && 2 * P <= 256) { P *= 2; ++lp; }
-  if (P > (ctx->num_cus > 0 ? ctx->num_cus : 256)) return false;
+  if (P > cus) return false;
   R.P = P;
   R.logP = lp;
   const int qn = (R.m + 255) / 256;
-  R.Q = qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8));
+  R.Q = R.reg ? (qn <= 10 ? 10 : 12) : (qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8)));
   const int ldr = 256 * R.Q, rmax = (R.m - 1) / P + 1;
-  R.lds = sizeof(double) * ((size_t)rmax * ldr + kResSmall);
+  R.lds = sizeof(double) * ((R.reg ? 0 : (size_t)rmax * ldr) + kResSmall);
   *out = R;
   return true;
 }
 
-template <int Q>
+template <int Q, int RR>
 static int launch_resident_q(sc_ctx* ctx, const ResArgs& g, const ResPlan& R, int batch) {
-  if (!sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_sytrd_resident<Q>), 160 * 1024)) return 1;
-  hipLaunchKernelGGL(k_sytrd_resident<Q>, dim3((unsigned)R.P, (unsigned)batch), dim3(256), R.lds, ctx->stream, g);
+  if (!sc_raise_dyn_lds(reinterpret_cast<const void*>(&k_sytrd_resident<Q, RR>), 160 * 1024)) return 1;
+  hipLaunchKernelGGL((k_sytrd_resident<Q, RR>), dim3((unsigned)R.P, (unsigned)batch), dim3(256), R.lds, ctx->stream, g);
   return SC_OK;
 }
 
@@ -1125,11 +1224,13 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
     SC_HIP(ctx, hipMemsetAsync(d_ws + (size_t)b * L.slab + L.rctl, 0xFF, tri_resident_bytes(L.n), st));
   int rc = 1;
   switch (R.Q) {
-    case 1: rc = launch_resident_q<1>(ctx, g, R, batch); break;
-    case 2: rc = launch_resident_q<2>(ctx, g, R, batch); break;
-    case 4: rc = launch_resident_q<4>(ctx, g, R, batch); break;
-    case 6: rc = launch_resident_q<6>(ctx, g, R, batch); break;
-    default: rc = launch_resident_q<8>(ctx, g, R, batch); break;
+    case 1: rc = launch_resident_q<1, 0>(ctx, g, R, batch); break;
+    case 2: rc = launch_resident_q<2, 0>(ctx, g, R, batch); break;
+    case 4: rc = launch_resident_q<4, 0>(ctx, g, R, batch); break;
+    case 6: rc = launch_resident_q<6, 0>(ctx, g, R, batch); break;
+    case 8: rc = launch_resident_q<8, 0>(ctx, g, R, batch); break;
+    case 10: rc = launch_resident_q<10, 10>(ctx, g, R, batch); break;
+    default: rc = launch_resident_q<12, 12>(ctx, g, R, batch); break;
   }
   if (rc != SC_OK) return rc;
   hipLaunchKernelGGL(k_sytrd_takeover, dim3((unsigned)batch), dim3(1024), 0, st, g);

@@ -58,10 +58,11 @@ def check(sc, a, tol=1e-11):
     return w
 
 
-@pytest.mark.parametrize("n", [128, 129, 255, 300, 513, 1000, 1537, 2048])
+@pytest.mark.parametrize("n", [128, 129, 255, 300, 513, 1000, 1537, 2048, 2049, 2561, 3072])
 def test_whole_matrix_in_one_launch(res, n):
     """Orders on both sides of every internal boundary: 256 columns per thread chunk, 8 rows per workgroup, odd orders,
-    the largest order that fits (2048); eigenvalues only and the partial spectrum take the same reduction."""
+    the largest order with the rows in LDS (2048), the two register forms (up to 2560 and up to 3072, the largest that
+    fits); eigenvalues only and the partial spectrum take the same reduction."""
     sc, counter, set_ = res
     a = sym(n, n)
     before = counter("resident_launches")
@@ -89,10 +90,10 @@ def test_workgroup_counts(res, wgs):
 
 
 def test_trailing_matrix_of_a_larger_order(res):
-    """n = 2300: four panels by the launches per column, the trailing matrix of order 2044 (lower triangle only valid
+    """n = 3300: four panels by the launches per column, the trailing matrix of order 3044 (lower triangle only valid
     behind the SYR2K updates) in one launch."""
     sc, counter, set_ = res
-    a = sym(11, 2300)
+    a = sym(11, 3300)
     before = counter("resident_launches")
     check(sc, a)
     assert counter("resident_launches") == before + 1
@@ -114,11 +115,12 @@ def test_scaled_input_and_only_the_lower_triangle(res):
     check_eigenvectors(a, w, v, tol_res=1e-11, tol_orth=1e-11)
 
 
-@pytest.mark.parametrize("n,hook", [(300, 1), (300, 2 + 150), (700, 2 + 0), (2300, 1)])
+@pytest.mark.parametrize("n,hook", [(300, 1), (300, 2 + 150), (700, 2 + 0), (2300, 2 + 40), (3200, 1)])
 def test_take_over(res, n, hook):
-    """The take-over kernel behind every launch: a failed roll call (nothing stored yet; also for a trailing matrix) and
-    a wait lost in mid-run (the matrix is restored from its other triangle) still give LAPACK's eigenpairs; the event is
-    counted and the context keeps to the launches per column until the debug entry re-arms it."""
+    """The take-over kernel behind every launch: a failed roll call (nothing stored yet; n = 3200: for a trailing matrix)
+    and a wait lost in mid-run (the matrix is restored from its other triangle; n = 2300: the register form) still give
+    LAPACK's eigenpairs; the event is counted and the context keeps to the launches per column until the debug entry
+    re-arms it."""
     sc, counter, set_ = res
     a = sym(n + hook, n)
     set_(1, hook)
@@ -136,7 +138,7 @@ def test_lost_wait_in_a_trailing_matrix_fails_the_solve(res):
     """A trailing matrix cannot be restarted (its upper triangle is stale): a wait lost in mid-run there surfaces as
     LinAlgError through the deferred status, as a QL failure would; the next solve is clean."""
     sc, counter, set_ = res
-    a = sym(13, 2300)
+    a = sym(13, 3200)
     set_(1, 2 + 500)
     with pytest.raises(np.linalg.LinAlgError):
         sc.nma.eigh(a)
