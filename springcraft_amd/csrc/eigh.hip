@@ -73,9 +73,10 @@ bool two_stage_for(const sc_ctx* ctx, int n, int batch) {
   // round 5 (profiles/r05_two_stage_crossover.txt; the panel QR of a few matrices by several workgroups of one launch,
   // k_panel_coop): one matrix ties at n = 4500 (124 vs 122 ms) and n = 6000 (191 vs 187), two-stage from there on (7500:
   // 310 vs 273, 9000: 441 vs 360, 12000: 856 vs 581); 2 x 4500: 157 vs 133, 8 x 1500: 43.5 vs 39.5
-  // round 6 (profiles/r06_two_stage_crossover.txt): ONE matrix whose trailing 2048 columns k_sytrd_resident reduces in
-  // one launch stays on the one-stage path up to n ~ 6300 (n = 4500: 98 vs 122 ms, 6000: 167 vs 177, 7500: 285 vs 248)
-  if (batch == 1 && resident_enabled(ctx)) return n > 6300;
+  // round 6 (profiles/r06_two_stage_crossover.txt): ONE matrix whose trailing 3072 columns k_sytrd_resident reduces in
+  // one launch stays on the one-stage path up to n ~ 7000 (n = 3000: 32 vs 71 ms, 5100: 110 vs 142, 6000: 152 vs 178,
+  // 6600: 196 vs 201, 7200: 233 vs 230, 7800: 285 vs 263)
+  if (batch == 1 && resident_enabled(ctx)) return n > 7000;
   return n >= 512 && (double)batch * n * n >= std::max(1.7e7, 5.0e3 * n);
 }
 

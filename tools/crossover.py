@@ -29,4 +29,6 @@ for n_atoms, B in ROWS:
         row.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "fail")
     n = 3 * n_atoms
     auto = "two" if (n >= 512 and B * n * n >= max(1.7e7, 5.0e3 * n)) else "one"   # eigh.hip:two_stage_for
+    if B == 1:
+        auto = "two" if n > 7000 else "one"   # (one matrix, with k_sytrd_resident)
     print(f"N={n_atoms:5d} n={n:5d} B={B:3d}: one-stage {row[0]:>8s} ms   two-stage {row[1]:>8s} ms   (automatic: {auto}-stage)", flush=True)
