@@ -268,8 +268,13 @@ int eigh_batched_async(sc_ctx* ctx, double* d_a, int64_t n64, int64_t batch64, d
     double* u = (double*)(base + P.off_u);
     GemmDesc* bt_descs = descs + P.n_syr2k + P.n_merge;
     const int bt_off = P.two ? sb_band_width() : 1;
-    // (one structure on the one-stage path: the fork / join costs more than the overlap brings, 30.0 -> 31.3 ms at N = 512)
-    const bool use_aux = !no_aux && (P.two || batch >= 4);
+    // (one structure on the one-stage path with its launches per column: the fork / join costs more than the overlap
+    // brings, 30.0 -> 31.3 ms at N = 512)
+    // (round 6: one structure whose tridiagonalisation is the single launch of k_sytrd_resident forks as well -- the T
+    // factors' 0.6 ms beside a D&C of 2 ms: N = 100 2.46 -> 1.88 ms, N = 512 9.23 -> 8.69; SPRINGCRAFT_AUX_SINGLE = 0 / 1)
+    static const int aux_single = [] { const char* e = getenv("SPRINGCRAFT_AUX_SINGLE"); return e ? atoi(e) : -1; }();
+    const bool single_fork = aux_single >= 0 ? aux_single != 0 : (batch == 1 && resident_enabled(ctx));
+    const bool use_aux = !no_aux && (P.two || batch >= 4 || single_fork);
     AuxJoinGuard aux{ctx, st};
     if (P.two && no_aux) {
       t_tf.reset(new PhaseTimer(ctx, "dia_tfactor", st));

@@ -23,4 +23,6 @@ t0 = time.perf_counter()
 for _ in range(reps):
     s.solve(x)
 torch.cuda.synchronize()
-print(f"N={n_atoms}: {(time.perf_counter() - t0) / reps * 1e3:.2f} ms per solve ({reps} solves enqueued back to back)", flush=True)
+dt = (time.perf_counter() - t0) / reps * 1e3
+print(f"N={n_atoms}: {dt:.2f} ms per solve ({reps} solves enqueued back to back); resident_launches "
+      f"{s.ctx.counter('resident_launches')}, resident_takeovers {s.ctx.counter('resident_takeovers')}", flush=True)
