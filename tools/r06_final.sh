@@ -13,6 +13,11 @@
 #   bash tools/r06_final.sh e   the spread chase on / off (C5, n = 12000, one N = 2000 structure); k_symm3: micro-bench (random and zero-like "hot" operands), loader-wave stamps, on / off in
 #                               the bench step and in C5 / C4 / C2; trailing update on 224 / 256 workgroups; D&C per level
 #   bash tools/r06_final.sh f   two-rank rehearsal on the shared GPU (bench.py --gpus 2, gloo)
+#   bash tools/r06_final.sh g   one structure at a time (k_sytrd_resident): accuracy and times against the launches per column
+#                               and numpy, both take-over routes, per-segment stamps (tools/build_res_stamps_lib.sh first),
+#                               the pause before the first poll, one- vs two-stage for one matrix, back-to-back stress,
+#                               rocprofv3 kernel statistics of single solves, the second stream on / off
+#   bash tools/r06_final.sh c5  the rows of the test matrix added with it
 # Everything lands in gpurun_out/r06_final/; what is to be judged is copied to profiles/r06_* (tools/r06_collect.sh).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -99,6 +104,36 @@ elif [ $part = e ]; then
   bash tools/r06_dc_levels.sh > $OUT/dc_levels.txt 2>&1
   cat $OUT/dc_levels.txt
   bash tools/r06_probe_i8.sh > /dev/null 2>&1; cp gpurun_out/r06/probe_i8_emulation.txt $OUT/probe_i8_emulation.txt; tail -12 $OUT/probe_i8_emulation.txt
+elif [ $part = g ]; then
+  timeout -k 10 600 python tools/resident_check.py 128 300 900 1536 2048 2560 3072 3300 2>&1 | grep -v amdgpu.ids > $OUT/resident_check.txt || exit 1
+  cat $OUT/resident_check.txt | cut -c1-220
+  SPRINGCRAFT_HIP_LIB=$ROOT/springcraft_amd/libspringcraft_hip_res_stamps.so timeout -k 10 300 python tools/resident_check.py --stamps 300 1536 2048 3000 2>&1 | grep "n=" > $OUT/resident_stamps.txt
+  cat $OUT/resident_stamps.txt
+  { for d in 0 8 16 24 32 48 64; do echo "== SPRINGCRAFT_RESIDENT_DELAY=$d"; SPRINGCRAFT_RESIDENT_DELAY=$d timeout -k 10 200 python tools/resident_check.py 300 1536 2048 2>&1 | grep "per-column" | cut -c1-75; done; } > $OUT/resident_delay.txt 2>&1
+  cat $OUT/resident_delay.txt
+  timeout -k 10 900 python tools/crossover.py --single 683 1000 1500 1700 2000 2200 2400 2600 2>&1 | grep "N=" > $OUT/two_stage_crossover.txt
+  cat $OUT/two_stage_crossover.txt
+  { timeout -k 10 300 python tools/resident_stress.py 512 30 20; timeout -k 10 300 python tools/resident_stress.py 300 30 20; timeout -k 10 300 python tools/resident_stress.py 1000 10 10; } 2>&1 | grep "N=" > $OUT/resident_stress.txt
+  cat $OUT/resident_stress.txt
+  { for a in 0 1 0 1; do for n in 100 300 512 1000; do SPRINGCRAFT_AUX_SINGLE=$a timeout -k 10 100 python tools/single_solves.py $n 20 2>&1 | grep "N=" | sed "s/^/SPRINGCRAFT_AUX_SINGLE=$a /"; done; done; } > $OUT/aux_single_ab.txt 2>&1
+  cat $OUT/aux_single_ab.txt
+  for n in 100 512 1000; do
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_single/n$n -o s --output-format csv -- \
+       python3 $ROOT/tools/single_solves.py $n 20 > $OUT/single_under_rocprof_$n.txt 2>&1) || { tail -5 $OUT/single_under_rocprof_$n.txt; exit 1; }
+    rm -f $OUT/prof_single/n$n/*kernel_trace.csv $OUT/prof_single/n$n/*/*kernel_trace.csv
+    cp $(ls -t $OUT/prof_single/n$n/*kernel_stats.csv $OUT/prof_single/n$n/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats_single_n$n.csv
+    grep "N=" $OUT/single_under_rocprof_$n.txt; head -3 $OUT/rocprofv3_kernel_stats_single_n$n.csv | cut -c1-160
+  done
+elif [ $part = c5 ]; then
+  T="tests/test_two_stage_gpu.py tests/test_eigh_gpu.py tests/test_batched_configs_gpu.py tests/test_gemm_gpu.py tests/test_resident_gpu.py"
+  row() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest $T -x -q -rf 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|error" | tail -4; }
+  { row SPRINGCRAFT_RESIDENT=0
+    row SPRINGCRAFT_AUX_SINGLE=0
+    row SPRINGCRAFT_RESIDENT_WGS=256 SPRINGCRAFT_RESIDENT_DELAY=0
+    row SPRINGCRAFT_RESIDENT_MAX=2048
+    row SPRINGCRAFT_TWO_STAGE=1
+    row SPRINGCRAFT_TWO_STAGE=0; } > $OUT/test_matrix_5.txt 2>&1
+  cat $OUT/test_matrix_5.txt
 else
   SPRINGCRAFT_BENCH_SHARE_GPUS=1 timeout -k 10 500 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/rehearsal_2ranks.json 2> $OUT/rehearsal_2ranks.err; echo "rehearsal rc $?"
   python tools/show_bench.py $OUT/rehearsal_2ranks.json
