@@ -298,59 +298,131 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
   }
   __syncthreads();
 
-  // ---- the deflation scan of dlaed2.  Its order matters only where two poles are close enough to be rotated into one
-  // (type 2): the rotation changes the pole the next comparison sees.  Round 6: the type-1 flags and the test of every pair
-  // of neighbouring survivors are evaluated by all threads first; when no pair is to be rotated -- the rule, away from
-  // clustered spectra -- the scan has nothing sequential left and the lists are written by all threads from prefix counts
-  // (one thread walking n elements was 0.3 ms per level at n = 1536, 1.8 of the 10.3 ms of a single N = 512 solve).
-  // Any rotation in the node: the scan below, unchanged.
+  // ---- the deflation scan of dlaed2.  Its order matters only along CHAINS of poles that are rotated into one another
+  // (type 2: the rotation changes the pole the next comparison sees).  Round 6: all threads evaluate the type-1 flags and
+  // the closeness test of every pair of neighbouring survivors on the values as sorted; the pairs that pass are the seeds
+  // of chains, which ONE thread follows in order (rotation, next survivor, test on the changed pole, ... until a test
+  // fails) -- work proportional to the rotations, not to the node --; then all threads write the lists from prefix counts.
+  // One thread walking the whole node (until round 6) was 0.3 us per element: 0.48 ms for the top level of one n = 1536
+  // matrix, 1.8 of the 10.3 ms of a single N = 512 solve.  Deflated entries are listed in index order (the scan listed a
+  // rotated-away pole when its partner was reached; k_dc_finalize ranks them, the order is free).
+  // sflag: bit 0 = type 1, bit 1 = seed, bit 2 = rotated away (type 2).
   const double tol = s_tol;
+  int* src = iptr(ws, DL.src);
+  int* rot_a = iptr(ws, DL.rot_a);
+  int* rot_b = iptr(ws, DL.rot_b);
+  int* cnt = iptr(ws, DL.cnt);
+  int* ktop_src = iptr(ws, DL.ktop_src);
+  int* ktop_k = iptr(ws, DL.ktop_k);
+  int* kbot_src = iptr(ws, DL.kbot_src);
+  int* kbot_k = iptr(ws, DL.kbot_k);
+  __shared__ int wsum[3][16];
+  __shared__ int s_nrot;
+  const int L = (N + nthr - 1) / nthr;
+  const int j0 = min(tid * L, N), j1 = min(j0 + L, N);
+
   for (int j = tid; j < N; j += nthr) sflag[j] = !(rho * fabs(sz[j]) > tol) ? 1 : 0;
+  if (tid == 0) s_nrot = 0;
   __syncthreads();
-  int any_rot = 0;
-  for (int jj = tid; jj < N; jj += nthr) {
-    if (sflag[jj]) continue;
+  int nseed = 0;
+  for (int jj = j0; jj < j1; ++jj) {
+    if (sflag[jj] & 1) continue;
     int pj = jj - 1;
-    while (pj >= 0 && sflag[pj]) --pj;
+    while (pj >= 0 && (sflag[pj] & 1)) --pj;
     if (pj < 0) continue;
     double s = sz[pj], c = sz[jj];
     const double tau = hypot(c, s);
     const double t = sd[jj] - sd[pj];
     c /= tau;
     s /= tau;
-    if (fabs(t * c * s) <= tol) any_rot = 1;
+    if (fabs(t * c * s) <= tol) { sflag[jj] |= 2; ++nseed; }
   }
-  any_rot = __syncthreads_or(any_rot);
-  if (!any_rot) {
-    int* src = iptr(ws, DL.src);
-    int* cnt = iptr(ws, DL.cnt);
-    int* ktop_src = iptr(ws, DL.ktop_src);
-    int* ktop_k = iptr(ws, DL.ktop_k);
-    int* kbot_src = iptr(ws, DL.kbot_src);
-    int* kbot_k = iptr(ws, DL.kbot_k);
-    __shared__ int wsum[2][16];
-    const int L = (N + nthr - 1) / nthr;
-    const int j0 = min(tid * L, N), j1 = min(j0 + L, N);
-    int ns = 0, nt = 0;   // survivors / survivors from the first child in this thread's stretch
-    for (int j = j0; j < j1; ++j)
-      if (!sflag[j]) { ++ns; nt += scol[j] < mid; }
-    int is = ns, it = nt;   // inclusive sums over the wave, then over the block
+  const int any_rot = __syncthreads_or(nseed);
+  if (any_rot) {
+    // the seeds in ascending order, into the (not yet written) kbot_k list of the node
+    int is = nseed;
     for (int off = 1; off < 64; off <<= 1) {
-      const int us = __shfl_up(is, off), ut = __shfl_up(it, off);
-      if ((tid & 63) >= off) { is += us; it += ut; }
+      const int us = __shfl_up(is, off);
+      if ((tid & 63) >= off) is += us;
     }
-    if ((tid & 63) == 63) { wsum[0][tid >> 6] = is; wsum[1][tid >> 6] = it; }
+    if ((tid & 63) == 63) wsum[0][tid >> 6] = is;
     __syncthreads();
-    int bs = 0, bt = 0, ts = 0, tt = 0;
+    int bs = 0, total = 0;
     for (int w = 0; w < (nthr >> 6); ++w) {
-      if (w < (tid >> 6)) { bs += wsum[0][w]; bt += wsum[1][w]; }
+      if (w < (tid >> 6)) bs += wsum[0][w];
+      total += wsum[0][w];
+    }
+    int pos = bs + is - nseed;
+    for (int jj = j0; jj < j1; ++jj)
+      if (sflag[jj] & 2) kbot_k[lo + pos++] = jj;
+    __syncthreads();
+    if (tid == 0) {
+      int nrot = 0, done_upto = -1;
+      for (int si = 0; si < total; ++si) {
+        int jj = kbot_k[lo + si];
+        if (jj <= done_upto) continue;        // reached by the chain of an earlier seed
+        int pj = jj - 1;
+        while (pj >= 0 && (sflag[pj] & 5)) --pj;   // (the survivor in front of a seed that no chain reached is unchanged)
+        while (true) {
+          double s = sz[pj], c = sz[jj];
+          const double tau = hypot(c, s);
+          const double t = sd[jj] - sd[pj];
+          c /= tau;
+          s /= tau;
+          done_upto = jj;
+          if (!(fabs(t * c * s) <= tol)) break;    // (never at a seed itself: same values as in the test above)
+          // close poles: rotate z_pj into z_jj (type-2 deflation)
+          sz[jj] = tau;
+          sz[pj] = 0.0;
+          rot_a[lo + nrot] = scol[pj];
+          rot_b[lo + nrot] = scol[jj];
+          ws[DL.rot_c + lo + nrot] = c;
+          ws[DL.rot_s + lo + nrot] = s;
+          ++nrot;
+          if (((scol[pj] < mid) != (scol[jj] < mid)) || smix[pj] || smix[jj]) { smix[jj] = 1; smix[pj] = 1; }
+          const double tt = sd[pj] * c * c + sd[jj] * s * s;
+          sd[jj] = sd[pj] * s * s + sd[jj] * c * c;
+          sd[pj] = tt;
+          sflag[pj] |= 4;
+          pj = jj;
+          ++jj;
+          while (jj < N && (sflag[jj] & 1)) ++jj;
+          if (jj >= N) break;
+        }
+      }
+      s_nrot = nrot;
+    }
+    __syncthreads();
+  }
+  {
+    // lists from prefix counts: survivors that stay (status 0), of those the ones with entries in the top / bottom rows
+    int ns = 0, nt = 0, nb = 0;
+    for (int j = j0; j < j1; ++j)
+      if (!(sflag[j] & 5)) {
+        const bool top = scol[j] < mid;
+        ++ns;
+        nt += (top || smix[j]) ? 1 : 0;
+        nb += (!top || smix[j]) ? 1 : 0;
+      }
+    int is = ns, it = nt, ib = nb;   // inclusive sums over the wave, then over the block
+    for (int off = 1; off < 64; off <<= 1) {
+      const int us = __shfl_up(is, off), ut = __shfl_up(it, off), ub = __shfl_up(ib, off);
+      if ((tid & 63) >= off) { is += us; it += ut; ib += ub; }
+    }
+    __syncthreads();   // (wsum[0] was read above)
+    if ((tid & 63) == 63) { wsum[0][tid >> 6] = is; wsum[1][tid >> 6] = it; wsum[2][tid >> 6] = ib; }
+    __syncthreads();
+    int bs = 0, bt = 0, bb = 0, ts = 0, tt = 0, tb = 0;
+    for (int w = 0; w < (nthr >> 6); ++w) {
+      if (w < (tid >> 6)) { bs += wsum[0][w]; bt += wsum[1][w]; bb += wsum[2][w]; }
       ts += wsum[0][w];
       tt += wsum[1][w];
+      tb += wsum[2][w];
     }
-    int K = bs + is - ns, K1 = bt + it - nt;
-    int K3 = K - K1, ndef = j0 - K;
+    int K = bs + is - ns, K1 = bt + it - nt, K3 = bb + ib - nb;
+    int ndef = j0 - K;
     for (int j = j0; j < j1; ++j) {
-      if (sflag[j]) {
+      if (sflag[j] & 5) {
         ws[DL.ddef + hi - 1 - ndef] = sd[j];
         src[hi - 1 - ndef] = scol[j];
         ++ndef;
@@ -358,90 +430,24 @@ __global__ __launch_bounds__(1024) void k_dc_setup(double* __restrict__ dc_all, 
         ws[DL.dl + lo + K] = sd[j];
         ws[DL.zz + lo + K] = sz[j];
         src[lo + K] = scol[j];
-        if (scol[j] < mid) { ktop_src[lo + K1] = scol[j]; ktop_k[lo + K1] = K; ++K1; }
-        else { kbot_src[lo + K3] = scol[j]; kbot_k[lo + K3] = K; ++K3; }
+        // blockdiag(Q1, Q2): a column from the first child is zero in the bottom rows and vice versa, unless a
+        // deflation rotation mixed it (dlaed2's column types 1 / 2 / 3): the two half-GEMMs only take what is non-zero
+        const bool top = scol[j] < mid;
+        if (top || smix[j]) { ktop_src[lo + K1] = scol[j]; ktop_k[lo + K1] = K; ++K1; }
+        if (!top || smix[j]) { kbot_src[lo + K3] = scol[j]; kbot_k[lo + K3] = K; ++K3; }
         ++K;
       }
     }
     if (tid == 0) {
       cnt[2 * g] = ts;
-      cnt[2 * g + 1] = 0;
+      cnt[2 * g + 1] = s_nrot;
       GemmDesc& Dt = descs[((size_t)b * nodes_in_level + g) * 2];      // top rows
       Dt.n = ts;
       Dt.k = tt;
       GemmDesc& Db = descs[((size_t)b * nodes_in_level + g) * 2 + 1];  // bottom rows
       Db.n = ts;
-      Db.k = ts - tt;
+      Db.k = tb;
     }
-    return;
-  }
-
-  if (tid == 0) {
-    int* src = iptr(ws, DL.src);
-    int* rot_a = iptr(ws, DL.rot_a);
-    int* rot_b = iptr(ws, DL.rot_b);
-    int* cnt = iptr(ws, DL.cnt);
-    int* ktop_src = iptr(ws, DL.ktop_src);
-    int* ktop_k = iptr(ws, DL.ktop_k);
-    int* kbot_src = iptr(ws, DL.kbot_src);
-    int* kbot_k = iptr(ws, DL.kbot_k);
-    int K = 0, ndef = 0, nrot = 0, K1 = 0, K3 = 0;
-    auto deflate = [&](int jj) {
-      ws[DL.ddef + hi - 1 - ndef] = sd[jj];
-      src[hi - 1 - ndef] = scol[jj];
-      ++ndef;
-    };
-    auto accept = [&](int jj) {
-      ws[DL.dl + lo + K] = sd[jj];
-      ws[DL.zz + lo + K] = sz[jj];
-      src[lo + K] = scol[jj];
-      // blockdiag(Q1, Q2): a column from the first child is zero in the bottom rows and vice versa, unless a
-      // deflation rotation mixed it (dlaed2's column types 1 / 2 / 3): the two half-GEMMs only take what is non-zero
-      const bool top = scol[jj] < mid;
-      if (top || smix[jj]) { ktop_src[lo + K1] = scol[jj]; ktop_k[lo + K1] = K; ++K1; }
-      if (!top || smix[jj]) { kbot_src[lo + K3] = scol[jj]; kbot_k[lo + K3] = K; ++K3; }
-      ++K;
-    };
-    int pj = -1;
-    for (int jj = 0; jj < N; ++jj) {
-      if (!(rho * fabs(sz[jj]) > tol)) {  // negligible z component (dlaed2 type-1 deflation)
-        deflate(jj);
-        continue;
-      }
-      if (pj < 0) { pj = jj; continue; }
-      double s = sz[pj], c = sz[jj];
-      const double tau = hypot(c, s);
-      const double t = sd[jj] - sd[pj];
-      c /= tau;
-      s /= tau;
-      if (fabs(t * c * s) <= tol) {  // close poles: rotate z_pj into z_jj (type-2 deflation)
-        sz[jj] = tau;
-        sz[pj] = 0.0;
-        rot_a[lo + nrot] = scol[pj];
-        rot_b[lo + nrot] = scol[jj];
-        ws[DL.rot_c + lo + nrot] = c;
-        ws[DL.rot_s + lo + nrot] = s;
-        ++nrot;
-        if (((scol[pj] < mid) != (scol[jj] < mid)) || smix[pj] || smix[jj]) { smix[jj] = 1; smix[pj] = 1; }
-        const double tt = sd[pj] * c * c + sd[jj] * s * s;
-        sd[jj] = sd[pj] * s * s + sd[jj] * c * c;
-        sd[pj] = tt;
-        deflate(pj);
-        pj = jj;
-      } else {
-        accept(pj);
-        pj = jj;
-      }
-    }
-    if (pj >= 0) accept(pj);
-    cnt[2 * g] = K;
-    cnt[2 * g + 1] = nrot;
-    GemmDesc& Dt = descs[((size_t)b * nodes_in_level + g) * 2];      // top rows
-    Dt.n = K;
-    Dt.k = K1;
-    GemmDesc& Db = descs[((size_t)b * nodes_in_level + g) * 2 + 1];  // bottom rows
-    Db.n = K;
-    Db.k = K3;
   }
 }
 

@@ -121,7 +121,11 @@ def test_take_over(res, n, hook):
     and a wait lost in mid-run (the matrix is restored from its other triangle; n = 2300: the register form) still give
     LAPACK's eigenpairs; the event is counted and the context keeps to the launches per column until the debug entry
     re-arms it."""
+    import os
+
     sc, counter, set_ = res
+    if hook > 1 and n > int(os.environ.get("SPRINGCRAFT_RESIDENT_MAX", "3072")):
+        pytest.skip("with this SPRINGCRAFT_RESIDENT_MAX the matrix is not reduced whole: a lost wait fails the solve (next test)")
     a = sym(n + hook, n)
     set_(1, hook)
     t0, l0 = counter("resident_takeovers"), counter("resident_launches")

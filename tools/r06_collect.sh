@@ -39,7 +39,7 @@ out = {"kernel": "k_bulge_pair<0> (unchanged since round 4)", "n": 6000, "batch"
 json.dump(out, open("profiles/r06_bulge_pmc_fetch_write.json", "w"), indent=1)
 print("bulge traffic / task bytes:", out["traffic_over_task_bytes"])
 PY
-{ echo "# bash tools/r06_final.sh c1 | c2 | c3 | c4 (tools/test_matrix.sh in four parts), then c0.  35 rows."
+{ echo "# bash tools/r06_final.sh c1 | c2 | c3 | c4 (tools/test_matrix.sh in four parts), then c0, then c5 (the rows added with k_sytrd_resident, on the final build).  39 rows."
   echo "# Three rows FAILED in their first run; the failing output is kept below, each with what was changed, and part c0 re-ran them"
   echo "# (and the two rows added after the spread chase was built) on the final build:"
   echo "#  * SPRINGCRAFT_BULGE_PERSISTENT=0 ... STREAMS=1: test_device_solve_only_enqueues_at_n6000 asserted three persistent-chase launches,"
@@ -51,7 +51,9 @@ PY
   echo "#  * SPRINGCRAFT_SYMM3=0: the unit tests of k_symm3 ran with the kernel switched off -- they skip there now."
   cat $F/test_matrix_1.txt $F/test_matrix_2.txt $F/test_matrix_3.txt $F/test_matrix_4.txt | grep -v "^part"
   echo "# ---- part c0: re-runs after the fixes + the two later rows"
-  grep -v "^part" $F/test_matrix_0.txt; } > $P/r06_test_matrix.txt
+  grep -v "^part" $F/test_matrix_0.txt
+  echo "# ---- part c5: the rows added with k_sytrd_resident (and the two rows that force a tridiagonalisation path), final build"
+  grep -v "^part" $F/test_matrix_5.txt; } > $P/r06_test_matrix.txt
 cp $F/spread_chase.txt $P/r06_spread_chase.txt
 grep -v "^rc 0$" $F/pair_stamps.txt | grep -v amdgpu.ids > $P/r06_pair_stamps.txt
 cp $F/pair_ab.txt $P/r06_pair_ab.txt
@@ -62,6 +64,25 @@ cp $F/pair_ab.txt $P/r06_pair_ab.txt
 cp $F/syr2k_wgs.txt $P/r06_syr2k_wgs.txt
 cp $F/dc_levels.txt $P/r06_dc_levels.txt
 cp $F/probe_i8_emulation.txt $P/r06_probe_i8_emulation.txt
+# ---- one structure at a time (part g)
+{ echo "# tools/resident_check.py (bash tools/r06_final.sh g): nma.eigh of one random symmetric matrix through the host API -- launches per"
+  echo "# column | k_sytrd_resident | numpy.linalg.eigh on the box's host -- and |dw| / residual / orthogonality of both device paths;"
+  echo "# then the two take-over routes at n = 300 (test hooks of sc_dbg_set_resident)."
+  cat $F/resident_check.txt; } > $P/r06_resident_check.txt
+{ echo "# tools/resident_check.py --stamps (library built with -DRES_STAMPS): s_memtime cycles of workgroup 0 per column step, by segment."
+  echo "# (the label '100 MHz' of the tool is wrong for this chip: the counter runs at the shader clock, ~2.4 GHz: 9436 cycles = 3.9 us)"
+  cat $F/resident_stamps.txt
+  echo; echo "# the pause between a step's publication and its first poll (SPRINGCRAFT_RESIDENT_DELAY, units of 64 cycles; default 24)"
+  cat $F/resident_delay.txt; } > $P/r06_resident_stamps.txt
+{ echo "# tools/crossover.py --single (one structure at a time, device solve incl. assembly, ms): one-stage (trailing 3072 columns by"
+  echo "# k_sytrd_resident) against two-stage; the automatic rule for one matrix is n > 7000 -> two-stage (eigh.hip:two_stage_for)"
+  cat $F/two_stage_crossover.txt; } > $P/r06_two_stage_crossover.txt
+{ echo "# tools/resident_stress.py: batches of solves enqueued back to back without synchronisation; a failed roll call would show as"
+  echo "# resident_takeovers > 0 and a batch many times slower than the others"
+  cat $F/resident_stress.txt
+  echo; echo "# tools/single_solves.py: the back-transformation's preparation on the main stream (0) / on the second stream beside the D&C (1, default)"
+  cat $F/aux_single_ab.txt; } > $P/r06_resident_stress.txt
+for n in 100 512 1000; do python3 tools/kernel_stats_summary.py $F/rocprofv3_kernel_stats_single_n$n.csv $n > $P/r06_rocprofv3_kernel_stats_single_n$n.txt; done
 line $F/rehearsal_2ranks.json > $P/r06_rehearsal_2ranks.json
 line $F/rehearsal_c4_2ranks.json > $P/r06_rehearsal_c4_2ranks.json
 ls -la $P/r06_* | awk '{print $5, $9}'
