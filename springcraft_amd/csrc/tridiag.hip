@@ -1206,6 +1206,30 @@ static int launch_resident_q(sc_ctx* ctx, const ResArgs& g, const ResPlan& R, in
   return SC_OK;
 }
 
+// Two launches of k_sytrd_resident must not run side by side: each wants every CU, both would sit in their roll calls with
+// half of their workgroups until one gives up.  Within a process the launches on a device are chained by an event: a
+// launch waits (on the device, in its stream) for the previous launch on that device, whatever context and stream it
+// came from.  (Another process on the same GPU is not seen: the roll call and the take-over are for that.)
+static int resident_chain(sc_ctx* ctx, hipStream_t st, bool before) {
+  static std::mutex mu;
+  static std::map<int, hipEvent_t> last;
+  static const bool off = getenv("SPRINGCRAFT_RESIDENT_NO_CHAIN") != nullptr;   // (diagnostic: what the chain is for)
+  if (off) return SC_OK;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = last.find(ctx->device);
+  if (before) {
+    if (it != last.end()) SC_HIP(ctx, hipStreamWaitEvent(st, it->second, 0));
+    return SC_OK;
+  }
+  if (it == last.end()) {
+    hipEvent_t e = nullptr;
+    SC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    it = last.emplace(ctx->device, e).first;
+  }
+  SC_HIP(ctx, hipEventRecord(it->second, st));
+  return SC_OK;
+}
+
 // SC_OK: enqueued (with its take-over); 1: not available on this device (the caller goes on with the launches per column)
 static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int batch, double* d_ws, const TriLayout& L,
                            const ResPlan& R) {
@@ -1222,6 +1246,7 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
   g.status = ctx->d_status;
   for (int b = 0; b < batch; ++b)
     SC_HIP(ctx, hipMemsetAsync(d_ws + (size_t)b * L.slab + L.rctl, 0xFF, tri_resident_bytes(L.n), st));
+  SC_TRY(resident_chain(ctx, st, true));
   int rc = 1;
   switch (R.Q) {
     case 1: rc = launch_resident_q<1, 0>(ctx, g, R, batch); break;
@@ -1235,6 +1260,7 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
   if (rc != SC_OK) return rc;
   hipLaunchKernelGGL(k_sytrd_takeover, dim3((unsigned)batch), dim3(1024), 0, st, g);
   SC_HIP(ctx, hipGetLastError());
+  SC_TRY(resident_chain(ctx, st, false));
   ++ctx->cnt_resident_launches;
   return SC_OK;
 }

@@ -148,3 +148,36 @@ def test_lost_wait_in_a_trailing_matrix_fails_the_solve(res):
         sc.nma.eigh(a)
     set_(1, 0)
     check(sc, sym(14, 300))
+
+
+def test_two_streams_of_single_solves_do_not_compete(res):
+    """
+    Two contexts on two streams enqueue single-structure solves at the same time (orders 2100: rows in registers, one
+    workgroup per CU; 1536: rows in LDS): launches of k_sytrd_resident on one device are chained by an event, so neither
+    sits in its roll call with half of its workgroups -- no take-over, eigenvalues as from one stream.
+    """
+    import torch
+
+    sc, counter, set_ = res
+    from springcraft_amd.batch import DeviceBatchSolver
+
+    for n_atoms in (700, 512):
+        coord = np.random.RandomState(3).rand(2, n_atoms, 3) * 5.0 * n_atoms ** (1 / 3)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        solvers, xs = [], []
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                solvers.append(DeviceBatchSolver(n_atoms, 1, sc.InvariantForceField(13.0)))
+                xs.append(torch.from_numpy(coord[k][None]).cuda())
+        torch.cuda.synchronize()
+        for _ in range(4):
+            for s, x, st in zip(solvers, xs, streams):
+                with torch.cuda.stream(st):
+                    s.solve(x)
+        torch.cuda.synchronize()
+        for k, s in enumerate(solvers):
+            w, _ = s.finish()
+            assert s.ctx.counter("resident_launches") == 4 and s.ctx.counter("resident_takeovers") == 0
+            h = sc.ANM(coord[k], sc.InvariantForceField(13.0)).hessian
+            w_ref = np.linalg.eigvalsh(h)
+            assert np.abs(w.cpu().numpy()[0] - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
