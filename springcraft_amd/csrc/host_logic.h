@@ -123,4 +123,45 @@ static inline int build_patch(const sc_patch_desc* pd, int64_t n, HostPatch& hp,
   return SC_OK;
 }
 
+
+// ---- k_sytrd_resident (tridiag.hip): which part of a one-matrix, one-stage solve it takes and with what launch shape.
+// Orders up to kResidentMaxLds keep the rows of the matrix in LDS (<= 8 rows of <= 2048 doubles per workgroup), up to
+// kResidentMaxReg in registers (<= 12 rows of 12 x 256 entries per thread; 256 workgroups, so a device with fewer CUs stays
+// with the LDS form); a larger matrix hands over its trailing columns at the first panel boundary (nb columns) from which
+// the order fits.  want_wgs: 0, or a number of workgroups to raise the minimum to (a power of two, <= 256).
+constexpr int kResidentRowsLds = 8, kResidentRowsReg = 12;
+constexpr int kResidentMaxLds = 2048, kResidentMaxReg = 3072;
+constexpr int kResidentSmallDoubles = 160;     // LDS besides the rows
+constexpr int kResidentMinOrder = 128;
+struct ResidentShape {
+  int off, m;        // the trailing matrix: rows / columns off .. off + m - 1
+  int P, logP;       // workgroups (a power of two)
+  int Q;             // template parameter: chunks of 256 columns per thread (1, 2, 4, 6, 8 | 10, 12)
+  bool reg;          // rows in registers
+  size_t lds_bytes;  // dynamic LDS of the launch
+};
+static inline bool resident_shape(int n, int nb, int cus, int max_order, int want_wgs, ResidentShape* out) {
+  if (n < kResidentMinOrder || nb <= 0) return false;
+  int max_m = cus >= 256 ? kResidentMaxReg : kResidentMaxLds;
+  if (max_order >= kResidentMinOrder && max_order < max_m) max_m = max_order;
+  ResidentShape R{};
+  R.off = n > max_m ? (n - max_m + nb - 1) / nb * nb : 0;
+  R.m = n - R.off;
+  if (R.m < kResidentMinOrder) return false;
+  R.reg = R.m > kResidentMaxLds;
+  const int rows = R.reg ? kResidentRowsReg : kResidentRowsLds;
+  int P = 32, lp = 5;
+  while ((R.m + P - 1) / P > rows) { P *= 2; ++lp; }
+  while (P < want_wgs && 2 * P <= 256) { P *= 2; ++lp; }
+  if (P > cus || P > 256) return false;
+  R.P = P;
+  R.logP = lp;
+  const int qn = (R.m + 255) / 256;
+  R.Q = R.reg ? (qn <= 10 ? 10 : 12) : (qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8)));
+  const size_t rmax = (size_t)(R.m - 1) / P + 1;
+  R.lds_bytes = sizeof(double) * ((R.reg ? 0 : rmax * 256 * R.Q) + kResidentSmallDoubles);
+  *out = R;
+  return true;
+}
+
 }  // namespace sc_host

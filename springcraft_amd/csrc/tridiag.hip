@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "eigh_internal.h"
+#include "host_logic.h"
 
 namespace {
 
@@ -560,9 +561,10 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 // launches; a trailing-matrix launch reports the failed solve through the status word).
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kResR = 8;                 // rows per workgroup at most
-constexpr int kResMaxLds = 2048;         // order of the (trailing) matrix at most with the rows in LDS: 8 rows of 8 x 256 entries
-constexpr int kResMaxM = 3072;           // ... with the rows in registers: 12 rows of 12 x 256 entries (256 workgroups)
-constexpr int kResSmall = 160;           // doubles of LDS besides the rows
+constexpr int kResMaxLds = sc_host::kResidentMaxLds;   // order of the (trailing) matrix at most with the rows in LDS: 8 rows of 8 x 256 entries
+constexpr int kResMaxM = sc_host::kResidentMaxReg;     // ... with the rows in registers: 12 rows of 12 x 256 entries (256 workgroups)
+constexpr int kResSmall = sc_host::kResidentSmallDoubles;   // doubles of LDS besides the rows
+static_assert(kResR == sc_host::kResidentRowsLds, "rows per workgroup");
 
 struct ResArgs {
   double* a;              // whole matrices, column-major, leading dimension L.n
@@ -1174,27 +1176,13 @@ bool resident_enabled(const sc_ctx* ctx) {
 }
 static bool resident_plan(sc_ctx* ctx, int n, int batch, int nb, ResPlan* out) {
   static const int env_wgs = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_WGS"); return e ? atoi(e) : 0; }();
-  if (!resident_enabled(ctx) || batch != 1 || n < 128) return false;
+  static const int env_max = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_MAX"); return e ? atoi(e) : 0; }();
+  if (!resident_enabled(ctx) || batch != 1) return false;
+  sc_host::ResidentShape S{};
+  const int want = ctx->resident_wgs > 0 ? ctx->resident_wgs : env_wgs;
+  if (!sc_host::resident_shape(n, nb, ctx->num_cus > 0 ? ctx->num_cus : 256, env_max, want, &S)) return false;
   ResPlan R{};
-  static const int env_max = [] { const char* e = getenv("SPRINGCRAFT_RESIDENT_MAX"); return e ? atoi(e) : kResMaxM; }();
-  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  int max_m = cus >= 256 ? kResMaxM : kResMaxLds;     // (the register form needs 256 workgroups)
-  if (env_max >= 128) max_m = std::min(max_m, env_max);
-  R.off = n > max_m ? (n - max_m + nb - 1) / nb * nb : 0;
-  R.m = n - R.off;
-  if (R.m < 128) return false;
-  R.reg = R.m > kResMaxLds;
-  int P = 32, lp = 5;
-  while ((R.m + P - 1) / P > (R.reg ? 12 : kResR)) { P *= 2; ++lp; }
-  const int want = ctx->resident_wgs > 0 ? ctx->resident_wgs : (env_wgs > 0 ? env_wgs : 0);
-  while (P < want && 2 * P <= 256) { P *= 2; ++lp; }
-  if (P > cus) return false;
-  R.P = P;
-  R.logP = lp;
-  const int qn = (R.m + 255) / 256;
-  R.Q = R.reg ? (qn <= 10 ? 10 : 12) : (qn <= 2 ? qn : (qn <= 4 ? 4 : (qn <= 6 ? 6 : 8)));
-  const int ldr = 256 * R.Q, rmax = (R.m - 1) / P + 1;
-  R.lds = sizeof(double) * ((R.reg ? 0 : (size_t)rmax * ldr) + kResSmall);
+  R.off = S.off; R.m = S.m; R.P = S.P; R.logP = S.logP; R.Q = S.Q; R.reg = S.reg; R.lds = S.lds_bytes;
   *out = R;
   return true;
 }

@@ -120,6 +120,36 @@ int main() {
     f.kind = SC_FF_TABULATED; f.tab = nullptr;
     CHECK(sc_host::check_ff(&f, err) == SC_ERR_INVALID_ARG);
   }
+  // ---- launch shape of k_sytrd_resident (one matrix resident on the chip: tridiag.hip)
+  {
+    using sc_host::ResidentShape;
+    ResidentShape S{};
+    CHECK(!sc_host::resident_shape(127, 64, 256, 0, 0, &S));                      // too small
+    CHECK(sc_host::resident_shape(128, 64, 256, 0, 0, &S) && S.off == 0 && S.m == 128 && S.P == 32 && S.Q == 1 && !S.reg);
+    CHECK(sc_host::resident_shape(300, 64, 256, 0, 0, &S) && S.P == 64 && S.logP == 6 && S.Q == 2);
+    CHECK(sc_host::resident_shape(300, 64, 256, 0, 256, &S) && S.P == 256 && S.logP == 8);      // more workgroups on request
+    CHECK(sc_host::resident_shape(1536, 64, 256, 0, 0, &S) && S.P == 256 && S.Q == 6 && !S.reg &&
+          S.lds_bytes == 8 * (size_t)(6 * 1536 + sc_host::kResidentSmallDoubles));
+    CHECK(sc_host::resident_shape(2048, 64, 256, 0, 0, &S) && S.Q == 8 && !S.reg && S.lds_bytes <= 160 * 1024);   // the LDS of a CU
+    CHECK(sc_host::resident_shape(2049, 64, 256, 0, 0, &S) && S.reg && S.Q == 10 && S.P == 256 && S.off == 0 &&
+          S.lds_bytes == 8 * (size_t)sc_host::kResidentSmallDoubles);
+    CHECK(sc_host::resident_shape(2561, 64, 256, 0, 0, &S) && S.reg && S.Q == 12);
+    CHECK(sc_host::resident_shape(3072, 64, 256, 0, 0, &S) && S.reg && S.off == 0 && (S.m + S.P - 1) / S.P <= sc_host::kResidentRowsReg);
+    // larger: the trailing matrix from the first panel boundary at which it fits
+    CHECK(sc_host::resident_shape(3073, 64, 256, 0, 0, &S) && S.off == 64 && S.m == 3009);
+    CHECK(sc_host::resident_shape(6000, 64, 256, 0, 0, &S) && S.off == 2944 && S.m == 3056 && S.reg);
+    CHECK(sc_host::resident_shape(6000, 64, 256, 2048, 0, &S) && S.off == 3968 && S.m == 2032 && !S.reg);   // SPRINGCRAFT_RESIDENT_MAX
+    // a device with fewer CUs has no register form and may not fit the workgroups at all
+    CHECK(sc_host::resident_shape(3000, 64, 128, 0, 0, &S) == false || (S.m <= 2048 && S.P <= 128));
+    CHECK(sc_host::resident_shape(1000, 64, 128, 0, 0, &S) && S.P == 128);
+    CHECK(!sc_host::resident_shape(2000, 64, 128, 0, 0, &S));                      // needs 256 workgroups
+    for (int n = 128; n <= 7000; n += 37) {
+      if (!sc_host::resident_shape(n, 64, 256, 0, 0, &S)) { CHECK(false); continue; }
+      const int rows = (S.m - 1) / S.P + 1;
+      CHECK(S.off % 64 == 0 && S.off + S.m == n && S.m <= 3072 && (1 << S.logP) == S.P && S.P <= 256);
+      CHECK(rows <= (S.reg ? 12 : 8) && 256 * S.Q >= S.m && S.lds_bytes <= 160 * 1024);
+    }
+  }
   std::puts("host logic ok");
   return 0;
 }
