@@ -817,12 +817,12 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       // predicated load would let the compiler touch the register early.  A lane without a record of its own reads record
       // c + 1: a record per wave for them, spread over the channels, measured no better -- 12.8 vs 12.6 ms at n = 1536)
       bool need[Q];
-      const v4i* ptr[Q];
+      unsigned ptr[Q];     // byte offsets from the buffer (a scalar base + a 32-bit lane offset: half the registers of pointers)
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int j = tid + 256 * q;
         need[q] = j > c && j < m;
-        ptr[q] = rb + (need[q] ? j : c + 1);
+        ptr[q] = 16u * (unsigned)(need[q] ? j : c + 1);
       }
       for (int dly = 0; dly < g.delay; ++dly) __builtin_amdgcn_s_sleep(1);
       v4i r4[Q];
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       bool lost = false;
       while (true) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r4[q]) : "v"(ptr[q]) : "memory");
+        for (int q = 0; q < Q; ++q) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(r4[q]) : "v"(ptr[q]), "s"(rb) : "memory");
         if constexpr (Q == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0])::"memory");
         if constexpr (Q == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1])::"memory");
         if constexpr (Q == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3])::"memory");
