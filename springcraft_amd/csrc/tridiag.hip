@@ -561,9 +561,9 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 // launches; a trailing-matrix launch reports the failed solve through the status word).
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kResR = 8;                 // rows per workgroup at most
-constexpr int kResMaxLds = sc_host::kResidentMaxLds;   // order of the (trailing) matrix at most with the rows in LDS: 8 rows of 8 x 256 entries
-constexpr int kResMaxM = sc_host::kResidentMaxReg;     // ... with the rows in registers: 12 rows of 12 x 256 entries (256 workgroups)
-constexpr int kResSmall = sc_host::kResidentSmallDoubles;   // doubles of LDS besides the rows
+// (orders: <= 2048 with the rows in LDS, 8 rows of 8 x 256 entries; <= 3072 with the rows in registers, 12 rows of 12 x 256
+// entries, 256 workgroups; the launch shape is decided in host_logic.h: resident_shape)
+constexpr int kResMaxM = sc_host::kResidentMaxReg;
 static_assert(kResR == sc_host::kResidentRowsLds, "rows per workgroup");
 
 struct ResArgs {
