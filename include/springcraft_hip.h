@@ -307,6 +307,9 @@ int sc_last_eigh_phase_ms(sc_ctx* ctx, const char* name, double* ms);
  *   "symm3_launches"   launches of the band reduction's symmetric product X = A22 V as one role-split kernel (k_symm3)
  *   "resident_launches" / "resident_takeovers"   one-stage reductions of one matrix done by the single launch that keeps
  *                      its rows in LDS (k_sytrd_resident), and those of them its take-over kernel had to do instead
+ *                      ("resident_rollcall_failures": because its workgroups were not all resident in time;
+ *                      "resident_lost_waits": because a wait between them ran into its bound; "resident_lost_at" = step << 32 | workgroup
+ *                      of that wait, resp. the workgroups that had arrived when the roll call was given up)
  *   "panel_coop_launches"   panel factorisations by the cooperative kernel (k_panel_coop: several workgroups of one launch)
  *   "panel_coop_timeouts"   panels (per matrix) the cooperative kernel gave up on -- a wait between its workgroups ran
  *                      into its bound; expected to stay 0 -- and the take-over launch behind it factored instead: the

@@ -120,8 +120,9 @@ int sc_dbg_set_panel_coop_fail(sc_ctx* ctx, int panel);
  * the trailing matrix of order <= 2048): mode 0 = never, 1 / -1 = the default rule (SPRINGCRAFT_RESIDENT).  hook: tests,
  * 1 = the roll call of its workgroups fails (nothing stored yet: k_sytrd_takeover reduces the matrix), 2 + c = the
  * exchange of step c fails (the take-over restores the matrix from its other triangle and starts again); 0 = none.
- * workgroups: 0 = by size, else a power of two (SPRINGCRAFT_RESIDENT_WGS).  Counters "resident_launches" /
- * "resident_takeovers".  tests/test_eigh_gpu.py */
+ * workgroups: 0 = by size, else a power of two (SPRINGCRAFT_RESIDENT_WGS).  Every call with mode != 0 re-arms a context
+ * that had given the kernel up (after a lost wait, or three failed roll calls).  Counters "resident_launches" /
+ * "resident_takeovers" / "resident_rollcall_failures" / "resident_lost_waits".  tests/test_resident_gpu.py */
 int sc_dbg_set_resident(sc_ctx* ctx, int mode, int hook, int workgroups);
 /* Library built with -DRES_STAMPS (else returns 1): cycles workgroup 0 of k_sytrd_resident spent in the segments of a
  * step -- [0] publish + poll of the records, [1] w~.v and the next column, [2] its norm, the next reflector and its

@@ -98,7 +98,12 @@ int sc_collect_events(sc_ctx* ctx) {
   ctx->cnt_coop_timeouts += (long long)h[5];
   ctx->cnt_chase_incomplete += (long long)h[6];
   ctx->cnt_resident_takeovers += (long long)h[7];
-  if (h[7]) ctx->resident_ok = 0;
+  ctx->cnt_resident_rollcalls += (long long)h[8];
+  ctx->cnt_resident_lost += (long long)h[9];
+  if (h[7]) ctx->resident_lost_at = (long long)h[10];
+  // (one failed roll call can be a launch whose workgroups were dispatched late; the context gives the kernel up at the third)
+  ctx->resident_strikes += (int)h[8];
+  if (h[9] || (h[8] && ctx->resident_strikes >= 3)) ctx->resident_ok = 0;
   // a context whose persistent kernels ran into a bound keeps to the launch-per-wavefront / chunked forms from here on
   if (h[3] || h[6]) ctx->chase_ok = 0;
   if (h[5]) ctx->coop_ok = 0;
@@ -460,6 +465,9 @@ int sc_ctx_get_counter(sc_ctx* ctx, const char* name, int64_t* value) {
   else if (k == "symm3_launches") *value = ctx->cnt_symm3_launches;
   else if (k == "resident_launches") *value = ctx->cnt_resident_launches;
   else if (k == "resident_takeovers") *value = ctx->cnt_resident_takeovers;
+  else if (k == "resident_rollcall_failures") *value = ctx->cnt_resident_rollcalls;
+  else if (k == "resident_lost_waits") *value = ctx->cnt_resident_lost;
+  else if (k == "resident_lost_at") *value = ctx->resident_lost_at;
   else if (k == "panel_coop_launches") *value = ctx->cnt_coop_launches;
   else if (k == "panel_coop_timeouts") *value = ctx->cnt_coop_timeouts;
   else if (k == "chase_timeouts") *value = ctx->cnt_chase_timeouts;
@@ -501,7 +509,7 @@ int sc_dbg_set_resident(sc_ctx* ctx, int mode, int hook, int workgroups) {
   ctx->resident_mode = mode;
   ctx->resident_hook = hook;
   ctx->resident_wgs = workgroups;
-  if (mode != 0) ctx->resident_ok = -1;
+  if (mode != 0) { ctx->resident_ok = -1; ctx->resident_strikes = 0; }
   return SC_OK;
 }
 

@@ -57,7 +57,8 @@ struct sc_ctx {
   // counters below at the next synchronising call): [2] persistent chases that k_chase_finish had to finish, [3] of
   // those: after a time-out (not the test hook), [4] sweeps the persistent kernels finished, [5] panels factored by
   // k_panel_serial after k_panel_coop gave up, [6] chases left incomplete without a raised flag (an XCD that owns
-  // matrices received no workgroup), [7] tridiagonalisations k_sytrd_takeover did after k_sytrd_resident gave up.
+  // matrices received no workgroup), [7] tridiagonalisations k_sytrd_takeover did after k_sytrd_resident gave up ([8] of
+  // those after an aborted roll call, [9] after a wait lost in mid-run, [10] where).
   unsigned long long* d_status = nullptr;
 
   int two_stage = -1;   // eigensolver path: -1 automatic, 0 one-stage, 1 two-stage tridiagonalisation
@@ -86,10 +87,12 @@ struct sc_ctx {
   int coop_attr = -1, coop_ok = -1;
   int coop_min_rows = -1;   // debug entry sc_dbg_set_panel_coop: rows from which a panel takes it (0 never, -1 default rule)
   int coop_fail_panel = -1; // debug entry sc_dbg_set_panel_coop_fail: panel from which the abort flags are raised (test hook)
-  // k_sytrd_resident (tridiag.hip): resident_ok = 0 once its workgroups were not all resident (the launches per column from
+  // k_sytrd_resident (tridiag.hip): resident_ok = 0 once a wait was lost or three roll calls failed (the launches per column from
   // then on); resident_mode / _hook / _wgs through the debug entry sc_dbg_set_resident (-1 / 0 / 0: the default rule)
   int resident_ok = -1, resident_mode = -1, resident_hook = 0, resident_wgs = 0;
-  long long cnt_resident_launches = 0, cnt_resident_takeovers = 0;
+  long long cnt_resident_launches = 0, cnt_resident_takeovers = 0, cnt_resident_rollcalls = 0, cnt_resident_lost = 0;
+  long long resident_lost_at = -1;   // (step << 32 | workgroup) of the most recent lost wait / arrivals at the last failed roll call
+  int resident_strikes = 0;          // failed roll calls since the kernel was (re-)armed: the context gives it up at the third
   int* last_chase_ctl = nullptr;   // control block of the most recent persistent chase (in dc_aux), read by sc_collect_events
   long long cnt_coop_launches = 0, cnt_coop_timeouts = 0;
   // event counters since the context was created (sc_ctx_get_counter)

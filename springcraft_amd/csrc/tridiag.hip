@@ -765,7 +765,9 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
     long spins = 0;
     if (k == 0) {
       bool all = false;
-      while (!all && spins < (1L << 17)) {
+      // (bound: ~2 s.  0.12 s was too tight: once in a few thousand launches some workgroups of a launch are dispatched that
+      // late on an otherwise idle GPU -- a single-stream stress run and one run of the suite each lost one roll call to it)
+      while (!all && spins < (1L << 21)) {
         all = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P - 1;
         ++spins;
         if (!all) __builtin_amdgcn_s_sleep(8);
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(256) void k_sytrd_resident(ResArgs g) {
       dec = old == -1 ? want : old;
     } else {
       while ((dec = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1) {
-        if (++spins > (1L << 21)) {
+        if (++spins > (1L << 23)) {
           const int old = atomicCAS(&ctl[0], -1, 2);
           dec = old == -1 ? 2 : old;
           break;
@@ -1069,7 +1071,12 @@ __global__ __launch_bounds__(1024) void k_sytrd_takeover(ResArgs g) {
     if (tid == 0) atomicMax(g.status + 1, 1ull);
     return;
   }
-  if (tid == 0) atomicAdd(g.status + 7, 1ull);
+  if (tid == 0) {
+    atomicAdd(g.status + 7, 1ull);
+    atomicAdd(g.status + (lost ? 9 : 8), 1ull);   // why: [8] the roll call was aborted, [9] a wait was lost in mid-run
+    // where: (step, workgroup) of the lost wait; the arrivals counted when the roll call was aborted
+    g.status[10] = lost ? (((unsigned long long)(unsigned)ctl[3] << 32) | (unsigned)ctl[4]) : (unsigned long long)(ctl[1] + 1);
+  }
   const double f = tri[g.L.hscale + 2];
   const bool bad = *reinterpret_cast<const unsigned long long*>(tri + g.L.hscale + 3) != 0ull;
   for (size_t idx = tid; idx < (size_t)m * m; idx += 1024) {
