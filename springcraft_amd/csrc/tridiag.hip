@@ -531,13 +531,13 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 }
 
 
-// ---- one matrix RESIDENT in LDS: the whole tridiagonalisation in one launch (round 6) -------------------------------
+// ---- one matrix RESIDENT on the chip: the whole tridiagonalisation in one launch (round 6) -------------------------------
 // The reference's own call is ONE structure at a time (anm.py:150-167, proteins of 100 - 1500 residues), and for one
-// matrix of order n <= 2048 the launches above are all latency: 3 dependent launches of 5 - 9 us per column, 25 ms at
-// n = 1536, whatever the kernels inside them do.  Here P <= 256 workgroups of ONE launch keep the matrix on the chip for
-// the whole reduction -- workgroup k holds the FULL rows k, k + P, k + 2P, ... (both triangles, <= 8 rows of <= 2048
-// doubles: <= 128 KB of LDS) -- and run LAPACK's unblocked dsytd2 recurrence with ONE exchange between the workgroups
-// per column:
+// matrix the launches above are all latency: 3 dependent launches of 5 - 9 us per column, 25 ms at n = 1536, whatever
+// the kernels inside them do.  Here P <= 256 workgroups of ONE launch keep the matrix on the chip for the whole
+// reduction -- workgroup k holds the FULL rows k, k + P, k + 2P, ... (both triangles): in LDS for orders <= 2048 (<= 8
+// rows of <= 2048 doubles: <= 128 KB), in registers for orders <= 3072 (<= 12 rows, thread t the entries t, t + 256, ...
+// of each) -- and run LAPACK's unblocked dsytd2 recurrence with ONE exchange between the workgroups per column:
 //   * every workgroup knows the current reflector v_c (registers: thread t holds the entries j = t, t + 256, ...) and
 //     has y_r = A[r, :] v_c for its own rows from the pass below;
 //   * it publishes, for each own row r, the 16-byte record { tau y_r , A[r, c+1] } (sc1 store: agent scope, visible to
@@ -546,8 +546,8 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 //   * from the records EVERY workgroup computes, redundantly and identically, w = w~ - (tau/2)(w~.v) v, the next column
 //     a = A[:, c+1] - v w[c+1] - w (by symmetry A[r, c+1] of row r's owner IS the column entry; v[c+1] = 1), its norm,
 //     the next reflector and tau: two workgroup-level reductions, no second exchange;
-//   * one pass over the own rows in LDS applies the rank-2 update A -= v w^T + w v^T and multiplies the updated rows
-//     with the NEXT reflector in the same sweep (the y of the next column).
+//   * one pass over the own rows applies the rank-2 update A -= v w^T + w v^T and multiplies the updated rows with the
+//     NEXT reflector in the same sweep (the y of the next column); a thread only ever touches its own entries of a row.
 // Three record buffers take turns: a row's owner empties the buffer of step c - 1 after its own poll of step c (by
 // then every workgroup has published step c, i.e. has finished reading step c - 1) and waits for that store before it
 // publishes step c + 1, so a reader of step c + 2 cannot see a record of step c - 1.
@@ -555,10 +555,11 @@ __global__ __launch_bounds__(256) void k_unscale_values(double* __restrict__ w_a
 // with the operands in a different order and may differ in the last bit: the reduction then is that of a matrix
 // A + E with |E| of the order of the rounding errors of the update itself.
 // All P workgroups must be resident together.  They check it BEFORE anything is stored (roll call: workgroup 0 counts
-// the arrivals within a bound and publishes go / abort in one word that a late comer can only read): after an abort the
-// matrix is untouched and k_sytrd_takeover, enqueued behind every launch, reduces it by one workgroup from memory; it also
-// restarts a reduction that lost a wait in mid-run when the upper triangle still holds the matrix (whole-matrix
-// launches; a trailing-matrix launch reports the failed solve through the status word).
+// the arrivals within a bound of about 2 s and publishes go / abort in one word that a late comer can only read): after
+// an abort the matrix is untouched and k_sytrd_takeover, enqueued behind every launch, reduces it by one workgroup from
+// memory; it also restarts a reduction that lost a wait in mid-run when the upper triangle still holds the matrix
+// (whole-matrix launches; a trailing-matrix launch reports the failed solve through the status word).  The launches of a
+// device are chained by an event (resident_chain below): two of them side by side would each hold half of the chip.
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kResR = 8;                 // rows per workgroup at most
 // (orders: <= 2048 with the rows in LDS, 8 rows of 8 x 256 entries; <= 3072 with the rows in registers, 12 rows of 12 x 256
