@@ -182,6 +182,7 @@ def test_two_streams_of_single_solves_do_not_compete(res):
         for k, st in enumerate(streams):
             with torch.cuda.stream(st):
                 solvers.append(DeviceBatchSolver(n_atoms, 1, sc.InvariantForceField(13.0)))
+                solvers[-1].ctx.set_two_stage(False)     # (whatever SPRINGCRAFT_TWO_STAGE says: the one-stage path is under test)
                 xs.append(torch.from_numpy(coord[k][None]).cuda())
         torch.cuda.synchronize()
         for _ in range(4):
