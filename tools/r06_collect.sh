@@ -61,7 +61,7 @@ PY
 cp $F/spread_chase.txt $P/r06_spread_chase.txt
 grep -v "^rc 0$" $F/pair_stamps.txt | grep -v amdgpu.ids > $P/r06_pair_stamps.txt
 # (the early-look run printed the label of the loader-wave run before it: tools/pair_stamps.py's default at the time)
-sed -i '/early look/{n;s/loader waves 1/loader waves 0/}' $P/r06_pair_stamps.txt
+sed -i '/^== early look/{n;s/loader waves 1/loader waves 0/}' $P/r06_pair_stamps.txt
 cp $F/pair_ab.txt $P/r06_pair_ab.txt
 { echo "== tools/symm3_bench.py (k_symm3 alone, random operands; last two lines: every column of A redirected to one hot column)"; cat $F/symm3_bench.txt
   echo; echo "== tools/r06_symm3_stamps.sh (first loader wave of every workgroup, one C3 step; second line: hot column)"; grep "^rc" $F/symm3_stamps.txt
