@@ -198,3 +198,35 @@ def test_two_streams_of_single_solves_do_not_compete(res):
             h = sc.ANM(coord[k], sc.InvariantForceField(13.0)).hessian
             w_ref = np.linalg.eigvalsh(h)
             assert np.abs(w.cpu().numpy()[0] - w_ref).max() <= 1e-11 * np.abs(w_ref).max()
+
+
+@pytest.mark.parametrize("n", [1536, 2600])
+@pytest.mark.parametrize("kind", ["ones", "four_eigenvalues", "clustered", "wilkinson", "six_zero_modes", "identity"])
+def test_degenerate_spectra_at_single_solve_orders(res, n, kind):
+    """Reflectors that vanish (identity), chains of deflation rotations (repeated and clustered eigenvalues: the D&C's
+    set-up walks them by one thread, everything else by all threads), exact null spaces -- at the orders a single solve
+    takes (1536: rows in LDS; 2600: rows in registers)."""
+    sc, counter, set_ = res
+    rs = np.random.RandomState(n)
+    if kind == "ones":
+        a = np.ones((n, n))
+    elif kind == "identity":
+        a = np.eye(n)
+    elif kind == "wilkinson":
+        a = np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    elif kind == "six_zero_modes":
+        b = rs.randn(n, n - 6)
+        a = b @ b.T
+    else:
+        q, _ = np.linalg.qr(rs.randn(n, n))
+        lam = np.repeat([1.0, 2.0, 3.0, 4.0], n // 4) if kind == "four_eigenvalues" else 1.0 + 1e-13 * np.arange(n)
+        a = (q * lam) @ q.T
+        a = (a + a.T) / 2
+    before = counter("resident_launches")
+    w, v = sc.nma.eigh(a)
+    assert counter("resident_launches") == before + 1 and counter("resident_takeovers") == 0
+    w_ref = np.linalg.eigvalsh(a)
+    scale = np.abs(w_ref).max()
+    assert np.abs(w - w_ref).max() <= 1e-11 * scale
+    assert np.abs(a @ v.T - v.T * w[None, :]).max() <= 1e-11 * scale
+    assert np.abs(v @ v.T - np.eye(n)).max() <= 1e-11
