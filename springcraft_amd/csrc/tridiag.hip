@@ -1206,12 +1206,13 @@ static int launch_resident_q(sc_ctx* ctx, const ResArgs& g, const ResPlan& R, in
 // half of their workgroups until one gives up.  Within a process the launches on a device are chained by an event: a
 // launch waits (on the device, in its stream) for the previous launch on that device, whatever context and stream it
 // came from.  (Another process on the same GPU is not seen: the roll call and the take-over are for that.)
+// The wait, the launch and the record of one solve are one critical section (g_resident_mu, taken by launch_resident):
+// two host threads with their own contexts would otherwise both wait for the same predecessor and then run side by side.
+static std::mutex g_resident_mu;
 static int resident_chain(sc_ctx* ctx, hipStream_t st, bool before) {
-  static std::mutex mu;
   static std::map<int, hipEvent_t> last;
   static const bool off = getenv("SPRINGCRAFT_RESIDENT_NO_CHAIN") != nullptr;   // (diagnostic: what the chain is for)
   if (off) return SC_OK;
-  std::lock_guard<std::mutex> g(mu);
   auto it = last.find(ctx->device);
   if (before) {
     if (it != last.end()) SC_HIP(ctx, hipStreamWaitEvent(st, it->second, 0));
@@ -1242,6 +1243,7 @@ static int launch_resident(sc_ctx* ctx, double* d_a, long long stride_a, int bat
   g.status = ctx->d_status;
   for (int b = 0; b < batch; ++b)
     SC_HIP(ctx, hipMemsetAsync(d_ws + (size_t)b * L.slab + L.rctl, 0xFF, tri_resident_bytes(L.n), st));
+  std::lock_guard<std::mutex> chain_lock(g_resident_mu);
   SC_TRY(resident_chain(ctx, st, true));
   int rc = 1;
   switch (R.Q) {
